@@ -1,0 +1,243 @@
+"""Generate the golden fixtures in this directory by IMPORTING THE REAL REFERENCE (jw9730/hot).
+
+Run only in the build container, where the reference checkout is mounted read-only:
+
+    PYTHONDONTWRITEBYTECODE=1 PYTHONPATH=/root/reference python tests/golden/make_golden.py
+
+The reference never travels to the GPU box; only the ``.npz`` files written here (inputs, weights
+and the reference's outputs / gradients) do.  Every file is plain numeric data loaded with
+``numpy.load(allow_pickle=False)``.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+from hot_pytorch.batch.sparse import Batch, make_batch, t, d, nd, v2d, batch_like  # noqa: E402
+from hot_pytorch.models.common.kernel import KernelFeatureMap  # noqa: E402
+from hot_pytorch.models.sparse.kernelattncoef import KernelFeatureMapWrapper, KernelAttnCoef  # noqa: E402
+from hot_pytorch.models.sparse.kernelattn import KernelSelfAttn  # noqa: E402
+from hot_pytorch.models.sparse.linear import Linear  # noqa: E402
+from hot_pytorch.models.encoder import EncLayer  # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def npy(x):
+    return x.detach().cpu().numpy()
+
+
+def rand_graphs(sizes, p, dn, de, seed, symmetric=False):
+    g = torch.Generator().manual_seed(seed)
+    nf, ei, ef = [], [], []
+    for n in sizes:
+        A = (torch.rand(n, n, generator=g) < p)
+        if symmetric:
+            A = A | A.t()
+        A = A & ~torch.eye(n, dtype=torch.bool)
+        idx = A.nonzero().t().contiguous()
+        nf.append(torch.randn(n, dn, generator=g))
+        ei.append(idx)
+        ef.append(torch.randn(idx.size(1), de, generator=g))
+    return nf, ei, ef
+
+
+def ba_graphs(n, count, dn, de, seed):
+    import networkx as nx
+    g = torch.Generator().manual_seed(seed)
+    nf, ei, ef = [], [], []
+    for s in range(count):
+        adj = nx.adjacency_matrix(nx.barabasi_albert_graph(n, 5, s)).tocoo()
+        idx = torch.tensor(np.vstack((adj.row, adj.col)), dtype=torch.long)
+        nf.append(torch.randn(n, dn, generator=g))
+        ei.append(idx)
+        ef.append(torch.randn(idx.size(1), de, generator=g))
+    return nf, ei, ef
+
+
+def pack_inputs(nf, ei, ef):
+    return dict(node_feature=npy(torch.cat(nf)), edge_index=npy(torch.cat(ei, 1)), edge_feature=npy(torch.cat(ef)),
+                n_nodes=np.array([x.size(0) for x in nf]), n_edges=np.array([e.size(0) for e in ef]))
+
+
+def ref_tests_transpose_fixture():
+    """The 4-graph fixture of the reference's own test_transpose (tests/test_sparse_util.py:37-57)."""
+    A1_nodes = torch.tensor([1, 5, 9, 0]); A1_edges = torch.tensor([[0, 2, 0, 3], [4, 0, 6, 7], [0, 8, 0, 8], [7, 0, 6, 0]])
+    A2_nodes = torch.tensor([1]); A2_edges = torch.tensor([[0]])
+    A3_nodes = torch.tensor([1, 0]); A3_edges = torch.tensor([[0, 2], [3, 0]])
+    A4_nodes = torch.tensor([1, 0]); A4_edges = torch.tensor([[0, 0], [2, 0]])
+    nodes = [A1_nodes, A2_nodes, A3_nodes, A4_nodes]
+    edges = [A1_edges, A2_edges, A3_edges, A4_edges]
+    nf = [x[:, None].repeat(1, 4).float() for x in nodes]
+    sp = [e.to_sparse().coalesce() for e in edges]
+    ei = [e.indices() for e in sp]
+    ef = [e.values()[:, None].repeat(1, 4).float() for e in sp]
+    return nf, ei, ef
+
+
+def dump_util(name, nf, ei, ef):
+    G = make_batch(nf, ei, ef)
+    out = pack_inputs(nf, ei, ef)
+    out.update(indices=npy(G.indices), values=npy(G.values), mask=npy(G.mask), node_mask=npy(G.node_mask),
+               t_indices=npy(G.t_indices), t_mask=npy(G.t_mask), node_ofs=npy(G.node_ofs),
+               sizes=np.array(G.n_edges),
+               t_values=npy(t(G).values), d_values=npy(d(G).values), nd_values=npy(nd(G).values),
+               v2d_values=npy(v2d(G, d(G)).values), tt_values=npy(t(t(G)).values))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def dump_linear(name, nf, ei, ef, dout, seed):
+    torch.manual_seed(seed)
+    G = make_batch(nf, ei, ef)
+    D = G.values.size(-1)
+    out = pack_inputs(nf, ei, ef)
+    for (oi, oo) in [(2, 2), (2, 1), (2, 0), (1, 1), (1, 0)]:
+        for cfg in ('light', 'default'):
+            for normalize in (True, False):
+                tag = f'l{oi}{oo}_{cfg}_{int(normalize)}'
+                lin = Linear(oi, oo, D, dout, bias=True, cfg=cfg, normalize=normalize)
+                for b in lin.bias.bias:
+                    torch.nn.init.normal_(b)
+                x = G.values.clone().requires_grad_(True)
+                Gin = batch_like(G, x, skip_masking=True)
+                if oi == 1:
+                    Gin = d(Gin)
+                captured = {}
+                if (oi, oo) == (2, 2):
+                    orig = lin.weight.get_output
+                    def hook(G_, vl, _o=orig, _c=captured):
+                        _c['V'] = [v.detach().clone() for v in vl]
+                        return _o(G_, vl)
+                    lin.weight.get_output = hook
+                y = lin(Gin)
+                yv = y if oo == 0 else y.values
+                R = torch.randn_like(yv)
+                (yv * R).sum().backward()
+                out[tag + '_w'] = npy(lin.weight.weight)
+                for k, b in enumerate(lin.bias.bias):
+                    out[tag + f'_b{k}'] = npy(b)
+                    out[tag + f'_gb{k}'] = npy(b.grad)
+                out[tag + '_y'] = npy(yv)
+                out[tag + '_R'] = npy(R)
+                out[tag + '_gx'] = npy(x.grad)
+                out[tag + '_gw'] = npy(lin.weight.weight.grad)
+                if 'V' in captured:
+                    out[tag + '_V'] = npy(torch.stack(captured['V'], 0))
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def dump_phi_coef(name, nf, ei, ef, d_head, n_heads, dv, seed):
+    """KernelFeatureMapWrapper for order 1/2 x query/key x generalized/softmax, and the seven
+    KernelAttnCoef cases of the reference's test_kernel_attn with random (not all-ones) inputs."""
+    torch.manual_seed(seed)
+    G2 = make_batch(nf, ei, ef)
+    B, E, _ = G2.values.shape
+    Nmax = G2.node_mask.size(1)
+    dqk = d_head * n_heads
+    out = pack_inputs(nf, ei, ef)
+    out['dims'] = np.array([d_head, n_heads, dv])
+    x2 = torch.randn(B, E, dqk)
+    x1 = torch.randn(B, Nmax, dqk)
+    v2 = torch.randn(B, E, dv)
+    v1 = torch.randn(B, Nmax, dv)
+    out.update(x1=npy(x1), x2=npy(x2), v1=npy(v1), v2=npy(v2))
+    X2 = batch_like(G2, x2)
+    X1 = Batch(None, x1, G2.n_nodes, None)
+    V2 = batch_like(G2, v2)
+    V1 = Batch(None, v1, G2.n_nodes, None)
+    for gen in (True, False):
+        fmap = KernelFeatureMap(d_head, generalized_attention=gen)
+        m = fmap.num_features
+        wrap = KernelFeatureMapWrapper(fmap, dqk, n_heads)
+        g = 'g' if gen else 's'
+        out[f'proj_{g}'] = npy(fmap.projection_matrix)
+        q1, k1 = wrap(X1, True), wrap(X1, False)
+        q2, k2 = wrap(X2, True), wrap(X2, False)
+        out[f'phi_{g}_q1'] = npy(q1.values); out[f'phi_{g}_k1'] = npy(k1.values)
+        out[f'phi_{g}_q2'] = npy(q2.values); out[f'phi_{g}_k2'] = npy(k2.values)
+        a11 = KernelAttnCoef(1, 1, m, dv, n_heads); a12 = KernelAttnCoef(1, 2, m, dv, n_heads)
+        a21 = KernelAttnCoef(2, 1, m, dv, n_heads); a22 = KernelAttnCoef(2, 2, m, dv, n_heads)
+        out[f'att_{g}_111'] = npy(a11(q1, k1, V1).values)
+        out[f'att_{g}_112_d12'] = npy(a11(q1, k1, V2, (1, 2)).values)
+        out[f'att_{g}_122'] = npy(a12(q1, k2, V2).values)
+        out[f'att_{g}_211'] = npy(a21(q2, k1, V1).values)
+        out[f'att_{g}_212_d13'] = npy(a21(q2, k1, V2, (1, 3)).values)
+        out[f'att_{g}_212_d23'] = npy(a21(q2, k1, V2, (2, 3)).values)
+        out[f'att_{g}_222'] = npy(a22(q2, k2, V2).values)
+        # list form: two tuples at once, second value transposed (as KernelSelfAttn uses it)
+        xq = torch.randn(B, E, dqk); xk = torch.randn(B, Nmax, dqk); vv = torch.randn(B, E, dv)
+        out[f'l_{g}_xq'] = npy(xq); out[f'l_{g}_xk'] = npy(xk); out[f'l_{g}_vv'] = npy(vv)
+        qb = wrap(batch_like(G2, xq), True); kb = wrap(Batch(None, xk, G2.n_nodes, None), False)
+        res = a21([q2, qb], [k1, kb], [V2, t(batch_like(G2, vv))], (2, 3))
+        out[f'l_{g}_o0'] = npy(res[0].values); out[f'l_{g}_o1'] = npy(res[1].values)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def dump_layer(name, nf, ei, ef, dim_qk, dim_v, n_heads, seed):
+    torch.manual_seed(seed)
+    G = make_batch(nf, ei, ef)
+    D = G.values.size(-1)
+    out = pack_inputs(nf, ei, ef)
+    out['dims'] = np.array([D, dim_v, dim_qk, n_heads])
+    d_head = dim_qk // n_heads
+    for gen in (True, False):
+        # cfg='local' is not captured: in the reference it fails with a shape error for (2,2) and (2,1)
+        # (fc_o is sized for all n_v terms but only the local ones are concatenated, kernelattn.py:49-50,146-158)
+        for (oi, oo, cfg) in [(2, 2, 'default'), (2, 1, 'default'), (1, 1, 'default')]:
+            tag = f"{'g' if gen else 's'}{oi}{oo}{cfg[0]}"
+            fmap = KernelFeatureMap(d_head, generalized_attention=gen)
+            layer = KernelSelfAttn(oi, oo, D, dim_v, dim_qk, n_heads, cfg, 0., 0., fmap)
+            for n_, p in layer.named_parameters():
+                if 'bias' in n_:
+                    torch.nn.init.normal_(p, std=0.1)
+            x = G.values.clone().requires_grad_(True)
+            Gin = batch_like(G, x, skip_masking=True)
+            if oi == 1:
+                Gin = d(Gin)
+            y = layer(Gin)
+            R = torch.randn_like(y.values)
+            (y.values * R).sum().backward()
+            for k, v in layer.state_dict().items():
+                out[f'{tag}/sd/{k}'] = npy(v)
+            for k, p in layer.named_parameters():
+                out[f'{tag}/grad/{k}'] = npy(p.grad)
+            out[f'{tag}/y'] = npy(y.values); out[f'{tag}/R'] = npy(R); out[f'{tag}/gx'] = npy(x.grad)
+    # one full EncLayer(2,2) with the generalized kernel
+    fmap = KernelFeatureMap(d_head, generalized_attention=True)
+    enc = EncLayer(2, 2, D, dim_qk, dim_v, 2 * D, n_heads, 'default', 'generalized_kernel', 0., 0., fmap, sparse=True)
+    x = G.values.clone().requires_grad_(True)
+    y = enc(batch_like(G, x, skip_masking=True))
+    R = torch.randn_like(y.values)
+    (y.values * R).sum().backward()
+    for k, v in enc.state_dict().items():
+        out[f'enc/sd/{k}'] = npy(v)
+    for k, p in enc.named_parameters():
+        out[f'enc/grad/{k}'] = npy(p.grad)
+    out['enc/y'] = npy(y.values); out['enc/R'] = npy(R); out['enc/gx'] = npy(x.grad)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def main():
+    torch.set_num_threads(4)
+    # F1/F2 index utilities
+    dump_util('util_reftest.npz', *ref_tests_transpose_fixture())
+    dump_util('util_random.npz', *rand_graphs([5, 1, 7, 3, 4, 6], 0.4, 3, 2, seed=11))
+    dump_util('util_ba64.npz', *ba_graphs(64, 2, 2, 2, seed=12))
+    # F3 linear basis
+    dump_linear('linear_random.npz', *rand_graphs([5, 1, 7, 2, 6], 0.45, 3, 3, seed=21), dout=5, seed=22)
+    dump_linear('linear_sym.npz', *rand_graphs([6, 4, 3], 0.5, 2, 2, seed=23, symmetric=True), dout=4, seed=24)
+    # F4/F5 feature maps and attention coefficients: odd sizes (d=4 -> m=5, dvh=3) and C1 sizes (d=8 -> m=16)
+    dump_phi_coef('coef_small.npz', *rand_graphs([2, 3, 4, 5], 0.5, 2, 2, seed=31), d_head=4, n_heads=3, dv=9, seed=32)
+    dump_phi_coef('coef_c1.npz', *rand_graphs([9, 6], 0.4, 2, 2, seed=33, symmetric=True), d_head=8, n_heads=4, dv=32, seed=34)
+    # F6/F7 layers
+    dump_layer('layer_small.npz', *rand_graphs([5, 3, 6, 1], 0.5, 4, 4, seed=41), dim_qk=8, dim_v=8, n_heads=2, seed=42)
+    dump_layer('layer_c1.npz', *ba_graphs(16, 2, 16, 16, seed=43), dim_qk=32, dim_v=32, n_heads=4, seed=44)
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith('.npz'):
+            print(f, os.path.getsize(os.path.join(HERE, f)))
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,151 @@
+"""CPU: the oracle (oracle/hot_oracle.py) against the golden vectors captured from the real reference
+and against the hand-written expected values of the reference's own tests."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, tt, rel_err
+from oracle import hot_oracle as O
+
+TOL = 1e-5  # fp32 relative tolerance named by BASELINE.json north_star
+
+
+def graph_inputs(z):
+    return (tt(z['node_feature']), tt(z['edge_index']), tt(z['edge_feature']),
+            [int(x) for x in z['n_nodes']], [int(x) for x in z['n_edges']])
+
+
+@pytest.mark.parametrize('name', ['util_reftest.npz', 'util_random.npz', 'util_ba64.npz'])
+def test_batch_and_index_utils_bit_exact(name):
+    z = load_golden(name)
+    G = O.build_batch(*graph_inputs(z))
+    for k, v in [('indices', G.indices), ('mask', G.mask), ('node_mask', G.node_mask),
+                 ('t_indices', G.t_indices), ('t_mask', G.t_mask), ('node_ofs', G.node_ofs)]:
+        assert np.array_equal(v.numpy(), z[k]), k
+    assert list(z['sizes']) == G.n_edges
+    assert np.array_equal(G.values.numpy(), z['values'])
+    assert np.array_equal(O.op_t(G).values.numpy(), z['t_values'])
+    assert np.array_equal(O.op_d(G).values.numpy(), z['d_values'])
+    assert np.array_equal(O.op_nd(G).values.numpy(), z['nd_values'])
+    assert np.array_equal(O.op_v2d(G, O.op_d(G)).values.numpy(), z['v2d_values'])
+    assert np.array_equal(O.op_t(O.op_t(G)).values.numpy(), z['tt_values'])
+
+
+def test_transpose_known_answer_from_reference_tests():
+    """Expected transposed adjacency written by hand in the reference (tests/test_sparse_util.py:61-76)."""
+    z = load_golden('util_reftest.npz')
+    G = O.build_batch(*graph_inputs(z))
+    GT = O.op_t(G)
+    expect = [np.array([[0, 4, 0, 7], [2, 0, 8, 0], [0, 6, 0, 6], [3, 0, 8, 0]]), np.array([[0]]),
+              np.array([[0, 3], [2, 0]]), np.array([[0, 0], [0, 0]])]
+    nodes = [np.array([1, 5, 9, 0]), np.array([1]), np.array([1, 0]), np.array([1, 0])]
+    for b, (e, x) in enumerate(zip(expect, nodes)):
+        n = len(x)
+        dense_e = np.zeros((n, n)); dense_n = np.zeros((n, n))
+        for r in range(G.n_edges[b]):
+            i, j = G.indices[b, r].tolist()
+            dense_n[i, j] += GT.values[b, r, 0].item()
+            dense_e[i, j] += GT.values[b, r, 4].item()
+        assert np.array_equal(dense_e, e) and np.array_equal(dense_n, np.diag(x))
+
+
+@pytest.mark.parametrize('name', ['linear_random.npz', 'linear_sym.npz'])
+def test_linear_basis_forward_backward(name):
+    z = load_golden(name)
+    G0 = O.build_batch(*graph_inputs(z))
+    for (oi, oo) in [(2, 2), (2, 1), (2, 0), (1, 1), (1, 0)]:
+        for cfg in ('light', 'default'):
+            for nrm in (1, 0):
+                tag = f'l{oi}{oo}_{cfg}_{nrm}'
+                x = G0.values.clone().requires_grad_(True)
+                G = G0.like(x)
+                if oi == 1:
+                    G = O.op_d(G)
+                w = tt(z[tag + '_w']).requires_grad_(True)
+                nb = 2 if oo == 2 else 1
+                bs = [tt(z[tag + f'_b{k}']).requires_grad_(True) for k in range(nb)]
+                y = O.linear_forward(G, oi, oo, w, bs, cfg, bool(nrm))
+                yv = y if oo == 0 else y.values
+                assert rel_err(yv, z[tag + '_y']) < TOL, tag
+                (yv * tt(z[tag + '_R'])).sum().backward()
+                assert rel_err(x.grad, z[tag + '_gx']) < TOL, tag
+                assert rel_err(w.grad, z[tag + '_gw']) < TOL, tag
+                for k in range(nb):
+                    assert rel_err(bs[k].grad, z[tag + f'_gb{k}']) < TOL, tag
+                if (oi, oo) == (2, 2):
+                    V = torch.stack(O.basis_2_to_2(G0, cfg, bool(nrm)), 0)
+                    assert rel_err(V, z[tag + '_V']) < TOL, tag
+
+
+@pytest.mark.parametrize('name', ['coef_small.npz', 'coef_c1.npz'])
+def test_feature_map_and_attention_coef(name):
+    z = load_golden(name)
+    G2 = O.build_batch(*graph_inputs(z))
+    d_head, H, dv = [int(x) for x in z['dims']]
+    dvh = dv // H
+    X2, V2 = G2.like(tt(z['x2']), True), G2.like(tt(z['v2']), True)
+    X1 = O.OBatch(None, tt(z['x1']), G2.n_nodes, None)
+    V1 = O.OBatch(None, tt(z['v1']), G2.n_nodes, None)
+    for g in ('g', 's'):
+        proj = tt(z[f'proj_{g}'])
+        m = proj.size(0)
+        fm = lambda X, q: O.feature_map_batch(X, proj, d_head, g == 'g', q)
+        q1, k1, q2, k2 = fm(X1, True), fm(X1, False), fm(X2, True), fm(X2, False)
+        for nm, val in [('q1', q1), ('k1', k1), ('q2', q2), ('k2', k2)]:
+            assert rel_err(val.values, z[f'phi_{g}_{nm}']) < TOL, (g, nm)
+        cases = {'111': (1, q1, k1, V1, None), '112_d12': (1, q1, k1, V2, (1, 2)), '122': (1, q1, k2, V2, None),
+                 '211': (2, q2, k1, V1, None), '212_d13': (2, q2, k1, V2, (1, 3)), '212_d23': (2, q2, k1, V2, (2, 3)),
+                 '222': (2, q2, k2, V2, None)}
+        for nm, (oq, q, k, v, dg) in cases.items():
+            out = O.kernel_attention(oq, q, k, v, m, dvh, dg)
+            assert rel_err(out.values, z[f'att_{g}_{nm}']) < TOL, (g, nm)
+        qb = fm(G2.like(tt(z[f'l_{g}_xq']), True), True)
+        kb = fm(O.OBatch(None, tt(z[f'l_{g}_xk']), G2.n_nodes, None), False)
+        vb = O.op_t(G2.like(tt(z[f'l_{g}_vv']), True))
+        o0, o1 = O.kernel_attention_list(2, [q2, qb], [k1, kb], [V2, vb], m, dvh, dv, (2, 3))
+        assert rel_err(o0.values, z[f'l_{g}_o0']) < TOL and rel_err(o1.values, z[f'l_{g}_o1']) < TOL
+
+
+def _sd(z, tag, grad=False):
+    pre = f'{tag}/sd/'
+    return {k[len(pre):]: tt(v).clone().requires_grad_(grad and v.dtype == np.float32 and 'projection' not in k)
+            for k, v in z.items() if k.startswith(pre)}
+
+
+@pytest.mark.parametrize('name', ['layer_small.npz', 'layer_c1.npz'])
+def test_kernel_self_attn_layer(name):
+    z = load_golden(name)
+    G0 = O.build_batch(*graph_inputs(z))
+    D, dim_v, dim_qk, H = [int(x) for x in z['dims']]
+    for g in ('g', 's'):
+        for (oi, oo) in [(2, 2), (2, 1), (1, 1)]:
+            tag = f'{g}{oi}{oo}d'
+            sd = _sd(z, tag, grad=True)
+            x = G0.values.clone().requires_grad_(True)
+            G = G0.like(x)
+            if oi == 1:
+                G = O.op_d(G)
+            y = O.kernel_self_attn(G, sd, oi, oo, D, dim_v, dim_qk, H, 'default', g == 'g')
+            assert rel_err(y.values, z[f'{tag}/y']) < TOL, tag
+            (y.values * tt(z[f'{tag}/R'])).sum().backward()
+            assert rel_err(x.grad, z[f'{tag}/gx']) < 2 * TOL, tag
+            for k, v in z.items():
+                if k.startswith(f'{tag}/grad/'):
+                    assert rel_err(sd[k[len(tag) + 6:]].grad, v) < 2 * TOL, k
+    # full encoder layer
+    sd = _sd(z, 'enc', grad=True)
+    x = G0.values.clone().requires_grad_(True)
+    y = O.enc_layer_2_2(G0.like(x), sd, D, dim_qk, dim_v, 2 * D, H)
+    assert rel_err(y.values, z['enc/y']) < TOL
+    (y.values * tt(z['enc/R'])).sum().backward()
+    assert rel_err(x.grad, z['enc/gx']) < 2 * TOL
+    for k, v in z.items():
+        if k.startswith('enc/grad/'):
+            assert rel_err(sd[k[len('enc/grad/'):]].grad, v) < 2 * TOL, k
+
+
+def test_ba_generator_shape():
+    ei = O.ba_edges(64, 5, np.random.default_rng(0))
+    assert ei.shape == (2, 590) and (ei[0] != ei[1]).all()
+    key = ei[0] * 64 + ei[1]
+    assert len(np.unique(key)) == 590 and np.array_equal(np.sort(key), np.sort(ei[1] * 64 + ei[0]))
