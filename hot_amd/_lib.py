@@ -1,0 +1,119 @@
+"""ctypes binding of libhotk.so (C ABI declared in include/hotk.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the shared object is missing,
+or a tensor handed to a kernel wrapper does not live on a HIP device, the call raises.
+"""
+import ctypes
+import os
+from ctypes import c_int, c_int64, c_size_t, c_uint, c_void_p, c_float
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libhotk.so')
+
+KEEP_PAD, KEEP_DIAG, KEEP_OFFDIAG = 1, 2, 4
+KEEP_VALID = KEEP_DIAG | KEEP_OFFDIAG
+SEG_CHUNK = 1024
+PHI_RELU, PHI_SOFTMAX_Q, PHI_SOFTMAX_K = 0, 1, 2
+
+_P, _I, _L, _U, _S, _F = c_void_p, c_int, c_int64, c_uint, c_size_t, c_float
+
+# name -> argtypes; every function returns int.  Order follows include/hotk.h.
+_SIGNATURES = {
+    'hotk_plan_workspace_bytes': [_L, _L, _L, _L, ctypes.POINTER(_S)],
+    'hotk_plan_build': [_P, _P, _P, _P, _L, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P],
+    'hotk_sort_workspace_bytes': [_L, ctypes.POINTER(_S)],
+    'hotk_sort_pairs_u32': [_P, _P, _L, _I, _P, _S, _P],
+    'hotk_gather_rows': [_P, _L, _P, _P, _L, _L, _L, _I, _P],
+    'hotk_mask_rows': [_P, _L, _P, _U, _F, _P, _L, _L, _L, _P],
+    'hotk_seg_sum_rows': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],
+    'hotk_bias_mask_rows': [_P, _L, _P, _P, _P, _L, _L, _P],
+    'hotk_bias_grad_rows': [_P, _L, _P, _P, _P, _L, _L, _P],
+    'hotk_basis22_light_fwd': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
+    'hotk_basis22_light_bwd': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
+    'hotk_phi_fwd': [_P, _L, _P, _P, _U, _P, _L, _L, _I, _I, _I, _I, _P, _P],
+    'hotk_phi_bwd': [_P, _L, _P, _P, _U, _P, _L, _P, _L, _L, _I, _I, _I, _I, _P, _P],
+    'hotk_phi_stats_workspace_bytes': [_L, _I, _I, ctypes.POINTER(_S)],
+    'hotk_phi_key_stats': [_P, _L, _P, _L, _I, _I, _I, _P, _P, _S, _P],
+    'hotk_phi_key_bwd_stats': [_P, _L, _P, _P, _U, _P, _L, _L, _I, _I, _I, _P, _P, _S, _P],
+    'hotk_seg_outer_sum': [_P, _L, _P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P],
+    'hotk_row_contract': [_P, _L, _P, _P, _P, _L, _P, _U, _P, _P, _L, _L, _I, _I, _I, _I, _P],
+    'hotk_apply_bwd_stats': [_P, _L, _P, _P, _L, _P, _U, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
+    'hotk_row_expand': [_P, _P, _L, _P, _L, _P, _P, _L, _P, _U, _P, _L, _L, _I, _I, _I, _P],
+}
+EXPORTS = sorted(list(_SIGNATURES) + ['hotk_strerror', 'hotk_version'])
+
+_lib = None
+
+
+class HotkError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libhotk.so once.  Raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HotkError(f'{LIB_PATH} is missing: hot_amd has no fallback path; build it with '
+                            f'`python -m hot_amd.build` (hipcc --offload-arch=gfx950)')
+        L = ctypes.CDLL(LIB_PATH)
+        for name, args in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.argtypes = args
+            fn.restype = c_int
+        L.hotk_strerror.argtypes = [c_int]
+        L.hotk_strerror.restype = ctypes.c_char_p
+        L.hotk_version.argtypes = []
+        L.hotk_version.restype = c_int
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise HotkError(f'{what} failed: {lib().hotk_strerror(rc).decode()} ({rc})')
+
+
+def require_device(t: torch.Tensor, what='tensor'):
+    if not t.is_cuda:
+        raise HotkError(f'hot_amd kernels run on a HIP device only; {what} is on {t.device}. '
+                        f'There is no CPU path: move the Batch / module to the GPU.')
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def p(t):
+    """device pointer of a tensor (storage offset included) or NULL"""
+    return c_void_p(0) if t is None else c_void_p(t.data_ptr())
+
+
+def rows2d(t: torch.Tensor):
+    """View [..., C] as rows: returns (tensor_keepalive, ld, n_rows, C).  Column slices of a contiguous
+    tensor are passed in place (ld = parent width); anything else is made contiguous first."""
+    require_device(t)
+    if t.dtype != torch.float32:
+        raise HotkError(f'fp32 tensors expected, got {t.dtype}')
+    C = t.size(-1)
+    n = t.numel() // C if C > 0 else 0
+    if t.dim() == 1:
+        t = t.unsqueeze(0)
+    ok = t.stride(-1) == 1 or C == 1
+    if ok:
+        ld = t.stride(-2) if t.dim() >= 2 else C
+        # leading dims must collapse onto the row stride
+        expect = ld
+        for k in range(t.dim() - 2, -1, -1):
+            if t.size(k) != 1 and t.stride(k) != expect:
+                ok = False
+                break
+            expect = expect * t.size(k)
+        if ld < C:
+            ok = False
+    if not ok:
+        t = t.contiguous()
+        ld = C
+    return t, int(ld), int(n), int(C)

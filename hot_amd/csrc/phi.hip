@@ -1,0 +1,362 @@
+// K2: FAVOR+ random-feature maps, fused with the head split and the loop/padding masks.
+// Reference: models/common/kernel.py:81-138 (softmax_map / generalized_map) and
+// models/sparse/kernelattncoef.py:19-28 (split into heads, loop mask, concat, padding mask).
+//
+// x [n, HH*d] -> phi [n, HH*m].  One thread per output feature (generalized map) or per (row, head)
+// (softmax maps, which need a max over the head's m features).  The projection matrix (m x d floats) is
+// staged in LDS once per block; x rows are read as whole contiguous pieces by consecutive lanes.
+#include "common.h"
+
+namespace {
+
+constexpr int PHI_THREADS = 256;
+constexpr int PHI_MAX_PROJ = 8192;  // floats of LDS for the projection matrix (m*d <= 8192)
+
+// one shared definition so that every kernel reproduces the projected value bit for bit
+__device__ __forceinline__ float proj_dot(const float* __restrict__ xr, const float* __restrict__ pr, int d,
+                                          float scale) {
+  float s = 0.f;
+  for (int k = 0; k < d; ++k) s = fmaf(xr[k] * scale, pr[k], s);
+  return s;
+}
+
+__device__ __forceinline__ void stage_proj(float* lds, const float* __restrict__ proj, int md) {
+  for (int i = threadIdx.x; i < md; i += blockDim.x) lds[i] = proj[i];
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------ generalized (ReLU) map
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd(const float* __restrict__ x, int64_t ld_x,
+                                                              const float* __restrict__ proj,
+                                                              const uint8_t* __restrict__ kind, unsigned keep,
+                                                              float* __restrict__ phi, int64_t ld_phi, int64_t n,
+                                                              int HH, int d, int m, float scale, float eps) {
+  __shared__ float P[PHI_MAX_PROJ];
+  stage_proj(P, proj, m * d);
+  const int64_t F = (int64_t)HH * m, total = n * F;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / F;
+    int f = (int)(t - r * F);
+    int hh = f / m, mm = f - hh * m;
+    float o = 0.f;
+    if (!kind || hotk_keep(keep, kind[r])) {
+      float pre = proj_dot(x + r * ld_x + hh * d, P + mm * d, d, scale);
+      o = fmaxf(pre, 0.f) + eps;
+    }
+    phi[r * ld_phi + f] = o;
+  }
+}
+
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_bwd(const float* __restrict__ x, int64_t ld_x,
+                                                              const float* __restrict__ proj,
+                                                              const uint8_t* __restrict__ kind, unsigned keep,
+                                                              const float* __restrict__ dphi, int64_t ld_dphi,
+                                                              float* __restrict__ dx, int64_t ld_dx, int64_t n, int HH,
+                                                              int d, int m, float scale) {
+  __shared__ float P[PHI_MAX_PROJ];
+  stage_proj(P, proj, m * d);
+  const int64_t C = (int64_t)HH * d, total = n * C;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / C;
+    int c = (int)(t - r * C);
+    int hh = c / d, k = c - hh * d;
+    float acc = 0.f;
+    if (!kind || hotk_keep(keep, kind[r])) {
+      const float* xr = x + r * ld_x + hh * d;
+      const float* gr = dphi + r * ld_dphi + hh * m;
+      for (int mm = 0; mm < m; ++mm) {
+        float pre = proj_dot(xr, P + mm * d, d, scale);
+        if (pre > 0.f) acc = fmaf(gr[mm], P[mm * d + k], acc);
+      }
+      acc *= scale;
+    }
+    dx[r * ld_dx + c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ softmax maps
+// mode 1 (query): stabiliser = max over the head's m features; mode 2 (key): stabiliser = gstat[0]
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_fwd(const float* __restrict__ x, int64_t ld_x,
+                                                                 const float* __restrict__ proj,
+                                                                 const uint8_t* __restrict__ kind, unsigned keep,
+                                                                 float* __restrict__ phi, int64_t ld_phi, int64_t n,
+                                                                 int HH, int d, int m, float scale, float eps,
+                                                                 float ratio, int mode,
+                                                                 const float* __restrict__ gstat) {
+  __shared__ float P[PHI_MAX_PROJ];
+  stage_proj(P, proj, m * d);
+  const int64_t total = n * HH;
+  const float gmax = (mode == HOTK_PHI_SOFTMAX_K) ? gstat[0] : 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / HH;
+    int hh = (int)(t - r * HH);
+    float* o = phi + r * ld_phi + (int64_t)hh * m;
+    if (kind && !hotk_keep(keep, kind[r])) {
+      for (int mm = 0; mm < m; ++mm) o[mm] = 0.f;
+      continue;
+    }
+    const float* xr = x + r * ld_x + hh * d;
+    float nrm = 0.f;
+    for (int k = 0; k < d; ++k) nrm = fmaf(xr[k], xr[k], nrm);
+    const float diag = nrm * 0.5f * scale * scale;
+    float stab = gmax;
+    if (mode == HOTK_PHI_SOFTMAX_Q) {
+      stab = -INFINITY;
+      for (int mm = 0; mm < m; ++mm) stab = fmaxf(stab, proj_dot(xr, P + mm * d, d, scale));
+    }
+    for (int mm = 0; mm < m; ++mm) {
+      float pre = proj_dot(xr, P + mm * d, d, scale);
+      o[mm] = ratio * (expf(pre - diag - stab) + eps);
+    }
+  }
+}
+
+// thread per (row, head, k)
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_bwd(const float* __restrict__ x, int64_t ld_x,
+                                                                 const float* __restrict__ proj,
+                                                                 const uint8_t* __restrict__ kind, unsigned keep,
+                                                                 const float* __restrict__ dphi, int64_t ld_dphi,
+                                                                 float* __restrict__ dx, int64_t ld_dx, int64_t n,
+                                                                 int HH, int d, int m, float scale, float ratio,
+                                                                 int mode, const float* __restrict__ gstat) {
+  __shared__ float P[PHI_MAX_PROJ];
+  stage_proj(P, proj, m * d);
+  const int64_t C = (int64_t)HH * d, total = n * C;
+  float gmax = 0.f, gshare = 0.f;
+  if (mode == HOTK_PHI_SOFTMAX_K) {
+    gmax = gstat[0];
+    gshare = gstat[1] / fmaxf(gstat[2], 1.f);  // d loss / d(-max), evenly split over the maxima
+  }
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / C;
+    int c = (int)(t - r * C);
+    int hh = c / d, k = c - hh * d;
+    const bool live = !kind || hotk_keep(keep, kind[r]);
+    const float* xr = x + r * ld_x + hh * d;
+    const float* gr = dphi + r * ld_dphi + (int64_t)hh * m;
+    float nrm = 0.f;
+    for (int kk = 0; kk < d; ++kk) nrm = fmaf(xr[kk], xr[kk], nrm);
+    const float diag = nrm * 0.5f * scale * scale;
+    float acc = 0.f, asum = 0.f;
+    if (mode == HOTK_PHI_SOFTMAX_Q) {
+      if (live) {
+        float stab = -INFINITY;
+        int arg = 0;
+        for (int mm = 0; mm < m; ++mm) {
+          float pre = proj_dot(xr, P + mm * d, d, scale);
+          if (pre > stab) { stab = pre; arg = mm; }
+        }
+        for (int mm = 0; mm < m; ++mm) {
+          float pre = proj_dot(xr, P + mm * d, d, scale);
+          float a = gr[mm] * ratio * expf(pre - diag - stab);
+          asum += a;
+          acc = fmaf(a, P[mm * d + k], acc);
+        }
+        acc -= asum * P[arg * d + k];
+      }
+    } else {
+      for (int mm = 0; mm < m; ++mm) {
+        float pre = proj_dot(xr, P + mm * d, d, scale);
+        float a = live ? gr[mm] * ratio * expf(pre - diag - gmax) : 0.f;
+        asum += a;
+        float dpre = a - ((pre == gmax) ? gshare : 0.f);
+        acc = fmaf(dpre, P[mm * d + k], acc);
+      }
+    }
+    dx[r * ld_dx + c] = scale * acc - asum * scale * scale * xr[k];
+  }
+}
+
+// ------------------------------------------------------------------ global statistics for the key branch
+__device__ __forceinline__ float block_reduce_max(float v, float* lds) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = lds[0];
+  for (int k = 1; k < (int)(blockDim.x >> 6); ++k) r = fmaxf(r, lds[k]);
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ float block_reduce_sum(float v, float* lds) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int k = 0; k < (int)(blockDim.x >> 6); ++k) r += lds[k];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_key_max_partial(const float* __restrict__ x, int64_t ld_x,
+                                                                     const float* __restrict__ proj, int64_t n, int HH,
+                                                                     int d, int m, float scale,
+                                                                     float* __restrict__ part) {
+  __shared__ float P[PHI_MAX_PROJ];
+  __shared__ float red[PHI_THREADS / 64];
+  stage_proj(P, proj, m * d);
+  const int64_t F = (int64_t)HH * m, total = n * F;
+  float mx = -INFINITY;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / F;
+    int f = (int)(t - r * F);
+    int hh = f / m, mm = f - hh * m;
+    mx = fmaxf(mx, proj_dot(x + r * ld_x + hh * d, P + mm * d, d, scale));
+  }
+  mx = block_reduce_max(mx, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = mx;
+}
+
+__global__ __launch_bounds__(PHI_THREADS) void k_reduce_max_final(const float* __restrict__ part, int nb,
+                                                                  float* __restrict__ out) {
+  __shared__ float red[PHI_THREADS / 64];
+  float mx = -INFINITY;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) mx = fmaxf(mx, part[i]);
+  mx = block_reduce_max(mx, red);
+  if (threadIdx.x == 0) out[0] = mx;
+}
+
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_key_bwd_partial(const float* __restrict__ x, int64_t ld_x,
+                                                                     const float* __restrict__ proj,
+                                                                     const uint8_t* __restrict__ kind, unsigned keep,
+                                                                     const float* __restrict__ dphi, int64_t ld_dphi,
+                                                                     int64_t n, int HH, int d, int m, float scale,
+                                                                     float ratio, const float* __restrict__ gstat,
+                                                                     float* __restrict__ part, int nb) {
+  __shared__ float P[PHI_MAX_PROJ];
+  __shared__ float red[PHI_THREADS / 64];
+  stage_proj(P, proj, m * d);
+  const float gmax = gstat[0];
+  const int64_t total = n * HH;
+  float s = 0.f, cnt = 0.f;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / HH;
+    int hh = (int)(t - r * HH);
+    const bool live = !kind || hotk_keep(keep, kind[r]);
+    const float* xr = x + r * ld_x + hh * d;
+    const float* gr = dphi + r * ld_dphi + (int64_t)hh * m;
+    float nrm = 0.f;
+    for (int k = 0; k < d; ++k) nrm = fmaf(xr[k], xr[k], nrm);
+    const float diag = nrm * 0.5f * scale * scale;
+    for (int mm = 0; mm < m; ++mm) {
+      float pre = proj_dot(xr, P + mm * d, d, scale);
+      if (pre == gmax) cnt += 1.f;
+      if (live) s += gr[mm] * ratio * expf(pre - diag - gmax);
+    }
+  }
+  s = block_reduce_sum(s, red);
+  cnt = block_reduce_sum(cnt, red);
+  if (threadIdx.x == 0) {
+    part[blockIdx.x] = s;
+    part[nb + blockIdx.x] = cnt;
+  }
+}
+
+__global__ __launch_bounds__(PHI_THREADS) void k_reduce_sum2_final(const float* __restrict__ part, int nb,
+                                                                   float* __restrict__ out) {
+  __shared__ float red[PHI_THREADS / 64];
+  float s = 0.f, c = 0.f;
+  for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+    s += part[i];
+    c += part[nb + i];
+  }
+  s = block_reduce_sum(s, red);
+  c = block_reduce_sum(c, red);
+  if (threadIdx.x == 0) {
+    out[1] = s;
+    out[2] = c;
+  }
+}
+
+constexpr int STATS_BLOCKS = 1024;
+
+int phi_check(int64_t n, int HH, int d, int m, int mode) {
+  if (n < 0 || HH <= 0 || d <= 0 || m <= 0) return HOTK_EINVAL;
+  if (mode < 0 || mode > 2) return HOTK_EINVAL;
+  if ((int64_t)m * d > PHI_MAX_PROJ) return HOTK_EUNSUPPORTED;
+  return HOTK_OK;
+}
+
+}  // namespace
+
+extern "C" int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind, unsigned keep,
+                            float* phi, int64_t ld_phi, int64_t n, int HH, int d, int m, int mode, const float* gstat,
+                            void* stream) {
+  int rc = phi_check(n, HH, d, m, mode);
+  if (rc) return rc;
+  if (n == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(x && proj && phi && ld_x >= (int64_t)HH * d && ld_phi >= (int64_t)HH * m);
+  HOTK_CHECK_ARG(mode != HOTK_PHI_SOFTMAX_K || gstat);
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = powf((float)d, -0.25f);
+  if (mode == HOTK_PHI_RELU) {
+    hipLaunchKernelGGL(k_phi_relu_fwd, dim3(hotk_grid(n * HH * m, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
+                       kind, keep, phi, ld_phi, n, HH, d, m, scale, 1e-3f);
+  } else {
+    hipLaunchKernelGGL(k_phi_softmax_fwd, dim3(hotk_grid(n * HH, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
+                       kind, keep, phi, ld_phi, n, HH, d, m, scale, 1e-4f, 1.0f / sqrtf((float)m), mode, gstat);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_phi_bwd(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind, unsigned keep,
+                            const float* dphi, int64_t ld_dphi, float* dx, int64_t ld_dx, int64_t n, int HH, int d,
+                            int m, int mode, const float* gstat, void* stream) {
+  int rc = phi_check(n, HH, d, m, mode);
+  if (rc) return rc;
+  if (n == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(x && proj && dphi && dx && ld_x >= (int64_t)HH * d && ld_dx >= (int64_t)HH * d &&
+                 ld_dphi >= (int64_t)HH * m);
+  HOTK_CHECK_ARG(mode != HOTK_PHI_SOFTMAX_K || gstat);
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = powf((float)d, -0.25f);
+  if (mode == HOTK_PHI_RELU) {
+    hipLaunchKernelGGL(k_phi_relu_bwd, dim3(hotk_grid(n * HH * d, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
+                       kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, d, m, scale);
+  } else {
+    hipLaunchKernelGGL(k_phi_softmax_bwd, dim3(hotk_grid(n * HH * d, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x,
+                       proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, d, m, scale, 1.0f / sqrtf((float)m), mode,
+                       gstat);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_phi_stats_workspace_bytes(int64_t n, int HH, int m, size_t* bytes) {
+  HOTK_CHECK_ARG(bytes);
+  (void)n; (void)HH; (void)m;
+  *bytes = 2 * STATS_BLOCKS * sizeof(float);
+  return HOTK_OK;
+}
+
+extern "C" int hotk_phi_key_stats(const float* x, int64_t ld_x, const float* proj, int64_t n, int HH, int d, int m,
+                                  float* gstat, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = phi_check(n, HH, d, m, HOTK_PHI_SOFTMAX_K);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(n > 0 && x && proj && gstat && workspace && ld_x >= (int64_t)HH * d);
+  if (ws_bytes < 2 * STATS_BLOCKS * sizeof(float)) return HOTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = powf((float)d, -0.25f);
+  int nb = (int)hotk_grid(n * HH * m, PHI_THREADS, STATS_BLOCKS);
+  hipLaunchKernelGGL(k_phi_key_max_partial, dim3(nb), dim3(PHI_THREADS), 0, st, x, ld_x, proj, n, HH, d, m, scale,
+                     (float*)workspace);
+  hipLaunchKernelGGL(k_reduce_max_final, dim3(1), dim3(PHI_THREADS), 0, st, (const float*)workspace, nb, gstat);
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_phi_key_bwd_stats(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind,
+                                      unsigned keep, const float* dphi, int64_t ld_dphi, int64_t n, int HH, int d,
+                                      int m, float* gstat, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = phi_check(n, HH, d, m, HOTK_PHI_SOFTMAX_K);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(n > 0 && x && proj && dphi && gstat && workspace && ld_x >= (int64_t)HH * d &&
+                 ld_dphi >= (int64_t)HH * m);
+  if (ws_bytes < 2 * STATS_BLOCKS * sizeof(float)) return HOTK_EWORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const float scale = powf((float)d, -0.25f);
+  int nb = (int)hotk_grid(n * HH, PHI_THREADS, STATS_BLOCKS);
+  hipLaunchKernelGGL(k_phi_key_bwd_partial, dim3(nb), dim3(PHI_THREADS), 0, st, x, ld_x, proj, kind, keep, dphi,
+                     ld_dphi, n, HH, d, m, scale, 1.0f / sqrtf((float)m), gstat, (float*)workspace, nb);
+  hipLaunchKernelGGL(k_reduce_sum2_final, dim3(1), dim3(PHI_THREADS), 0, st, (const float*)workspace, nb, gstat);
+  return hotk_launch_status();
+}

@@ -1,0 +1,323 @@
+// K4: coalesced row gather / mask / segment-sum primitives and the 'light' order-2 basis.
+// Every kernel maps consecutive lanes to consecutive channels of one row, so each wave instruction
+// touches whole 256-B (scalar) or 1-KiB (float4) row pieces; index arrays are read once per row piece.
+#include "common.h"
+
+namespace {
+
+template <int V> struct VecT;
+template <> struct VecT<1> { using type = float; };
+template <> struct VecT<4> { using type = float4; };
+
+__device__ __forceinline__ float vzero(float) { return 0.f; }
+__device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+__device__ __forceinline__ float vfill(float, float f) { return f; }
+__device__ __forceinline__ float4 vfill(float4, float f) { return make_float4(f, f, f, f); }
+
+// ------------------------------------------------------------------ gather
+template <int V>
+__global__ void k_gather_rows(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ idx,
+                              float* __restrict__ out, int64_t ld_out, int64_t n_out, int64_t CV, int accumulate) {
+  using T = typename VecT<V>::type;
+  const int64_t total = n_out * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / CV, c = (t - r * CV) * V;
+    int64_t s = idx ? (int64_t)idx[r] : r;
+    T v = vzero(T());
+    if (s >= 0) v = *reinterpret_cast<const T*>(src + s * ld_src + c);
+    T* o = reinterpret_cast<T*>(out + r * ld_out + c);
+    *o = accumulate ? vadd(*o, v) : v;
+  }
+}
+
+// ------------------------------------------------------------------ mask
+template <int V>
+__global__ void k_mask_rows(const float* __restrict__ src, int64_t ld_src, const uint8_t* __restrict__ kind,
+                            unsigned keep, float fill, float* __restrict__ out, int64_t ld_out, int64_t n, int64_t CV) {
+  using T = typename VecT<V>::type;
+  const int64_t total = n * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / CV, c = (t - r * CV) * V;
+    T v = hotk_keep(keep, kind[r]) ? *reinterpret_cast<const T*>(src + r * ld_src + c) : vfill(T(), fill);
+    *reinterpret_cast<T*>(out + r * ld_out + c) = v;
+  }
+}
+
+// ------------------------------------------------------------------ segment sum of rows
+// work item = (segment, chunk, channel-vector); a segment longer than HOTK_SEG_CHUNK is split and the
+// chunks are combined with float atomics into the (zero-filled) output.
+template <int V>
+__global__ void k_seg_sum_rows(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ seg_begin,
+                               const int32_t* __restrict__ seg_end, const int32_t* __restrict__ perm,
+                               const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out,
+                               int64_t ld_out, int64_t n_seg, int64_t CV, int64_t n_chunk) {
+  using T = typename VecT<V>::type;
+  const int64_t total = n_seg * n_chunk * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t cv = t % CV;
+    int64_t rest = t / CV;
+    int64_t ch = rest % n_chunk, s = rest / n_chunk;
+    int64_t b = seg_begin[s], e = seg_end[s];
+    int64_t lo = b + ch * HOTK_SEG_CHUNK, hi = lo + HOTK_SEG_CHUNK;
+    if (hi > e) hi = e;
+    if (lo >= hi && ch > 0) continue;
+    T acc = vzero(T());
+    for (int64_t p = lo; p < hi; ++p) {
+      int64_t r = perm ? (int64_t)perm[p] : p;
+      if (kind && !hotk_keep(keep, kind[r])) continue;
+      acc = vadd(acc, *reinterpret_cast<const T*>(src + r * ld_src + cv * V));
+    }
+    float* o = out + s * ld_out + cv * V;
+    if (e - b <= HOTK_SEG_CHUNK) {
+      *reinterpret_cast<T*>(o) = acc;
+    } else {
+      const float* a = reinterpret_cast<const float*>(&acc);
+#pragma unroll
+      for (int k = 0; k < V; ++k) atomicAdd(o + k, a[k]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ bias + mask (in place)
+template <int V>
+__global__ void k_bias_mask_rows(float* __restrict__ y, int64_t ld, const uint8_t* __restrict__ kind,
+                                 const float* __restrict__ b_off, const float* __restrict__ b_diag, int64_t n,
+                                 int64_t CV) {
+  using T = typename VecT<V>::type;
+  const int64_t total = n * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / CV, c = (t - r * CV) * V;
+    uint8_t kd = kind[r];
+    T* p = reinterpret_cast<T*>(y + r * ld + c);
+    T v = vzero(T());
+    if (kd != 0) {
+      v = *p;
+      const float* b = (kd == 2) ? b_off : b_diag;
+      if (b) v = vadd(v, *reinterpret_cast<const T*>(b + c));
+    }
+    *p = v;
+  }
+}
+
+// db[k][c] += sum over rows of kind k+... : block handles a strip of rows for all channels
+__global__ __launch_bounds__(256) void k_bias_grad_rows(const float* __restrict__ dy, int64_t ld,
+                                                        const uint8_t* __restrict__ kind, float* __restrict__ db_off,
+                                                        float* __restrict__ db_diag, int64_t n, int64_t C,
+                                                        int64_t rows_per_block) {
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
+    float a_off = 0.f, a_diag = 0.f;
+    for (int64_t r = r0; r < r1; ++r) {
+      uint8_t kd = kind[r];
+      if (kd == 0) continue;
+      float v = dy[r * ld + c];
+      if (kd == 2) a_off += v; else a_diag += v;
+    }
+    if (db_off) atomicAdd(db_off + c, a_off);
+    if (db_diag) atomicAdd(db_diag + c, a_diag);
+  }
+}
+
+// ------------------------------------------------------------------ order-2 'light' basis
+template <int V>
+__global__ void k_basis22_light_fwd(const float* __restrict__ x, int64_t ld_x, const uint8_t* __restrict__ kind,
+                                    const int32_t* __restrict__ rown, const int32_t* __restrict__ coln,
+                                    const int32_t* __restrict__ tpos, const int32_t* __restrict__ diag_pos,
+                                    float* __restrict__ x5, int64_t ld_x5, int64_t R, int64_t D) {
+  using T = typename VecT<V>::type;
+  const int64_t DV = D / V, total = R * DV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / DV, c = (t - r * DV) * V;
+    uint8_t kd = kind[r];
+    T z = vzero(T());
+    T v1 = z, v2 = z, v3 = z, v4 = z, v5 = z;
+    if (kd == 1) {
+      v1 = *reinterpret_cast<const T*>(x + r * ld_x + c);
+    } else if (kd == 2) {
+      v2 = *reinterpret_cast<const T*>(x + r * ld_x + c);
+      int32_t tp = tpos[r];
+      if (tp >= 0) v3 = *reinterpret_cast<const T*>(x + (int64_t)tp * ld_x + c);
+      v4 = *reinterpret_cast<const T*>(x + (int64_t)diag_pos[rown[r]] * ld_x + c);
+      v5 = *reinterpret_cast<const T*>(x + (int64_t)diag_pos[coln[r]] * ld_x + c);
+    }
+    float* o = x5 + r * ld_x5 + c;
+    *reinterpret_cast<T*>(o) = v1;
+    *reinterpret_cast<T*>(o + D) = v2;
+    *reinterpret_cast<T*>(o + 2 * D) = v3;
+    *reinterpret_cast<T*>(o + 3 * D) = v4;
+    *reinterpret_cast<T*>(o + 4 * D) = v5;
+  }
+}
+
+template <int V>
+__global__ void k_basis22_light_bwd(const float* __restrict__ g, int64_t ld_g, const uint8_t* __restrict__ kind,
+                                    const int32_t* __restrict__ rown, const int32_t* __restrict__ tpos,
+                                    const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ row_perm,
+                                    const int32_t* __restrict__ col_ptr, const int32_t* __restrict__ col_perm,
+                                    float* __restrict__ dx, int64_t ld_dx, int64_t R, int64_t D) {
+  using T = typename VecT<V>::type;
+  const int64_t DV = D / V, total = R * DV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / DV, c = (t - r * DV) * V;
+    uint8_t kd = kind[r];
+    T acc = vzero(T());
+    if (kd == 2) {
+      acc = *reinterpret_cast<const T*>(g + r * ld_g + D + c);
+      int32_t tp = tpos[r];  // x_r is the transposed input of row tp
+      if (tp >= 0) acc = vadd(acc, *reinterpret_cast<const T*>(g + (int64_t)tp * ld_g + 2 * D + c));
+    } else if (kd == 1) {
+      acc = *reinterpret_cast<const T*>(g + r * ld_g + c);
+      int32_t nd = rown[r];
+      for (int32_t p = row_ptr[nd]; p < row_ptr[nd + 1]; ++p) {  // x_(i,i) broadcast along row i
+        int32_t e = row_perm[p];
+        if (kind[e] == 2) acc = vadd(acc, *reinterpret_cast<const T*>(g + (int64_t)e * ld_g + 3 * D + c));
+      }
+      for (int32_t p = col_ptr[nd]; p < col_ptr[nd + 1]; ++p) {  // x_(j,j) broadcast along column j
+        int32_t e = col_perm[p];
+        if (kind[e] == 2) acc = vadd(acc, *reinterpret_cast<const T*>(g + (int64_t)e * ld_g + 4 * D + c));
+      }
+    }
+    *reinterpret_cast<T*>(dx + r * ld_dx + c) = acc;
+  }
+}
+
+inline bool vec4_ok(int64_t C, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
+  if (C % 4) return false;
+  for (int64_t l : lds) if (l % 4) return false;
+  for (const void* p : ptrs) if (p && !hotk_aligned16(p)) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" const char* hotk_strerror(int code) {
+  switch (code) {
+    case HOTK_OK: return "ok";
+    case HOTK_EINVAL: return "invalid argument";
+    case HOTK_EWORKSPACE: return "workspace too small";
+    case HOTK_ELAUNCH: return "HIP launch/runtime error";
+    case HOTK_EUNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+
+extern "C" int hotk_version(void) { return 100; }
+
+extern "C" int hotk_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, float* out, int64_t ld_out,
+                                int64_t n_out, int64_t C, int accumulate, void* stream) {
+  HOTK_CHECK_ARG(n_out >= 0 && C >= 0 && ld_src >= C && ld_out >= C);
+  if (n_out == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(src && out);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(C, {ld_src, ld_out}, {src, out})) {
+    hipLaunchKernelGGL(k_gather_rows<4>, dim3(hotk_grid(n_out * (C / 4), 256)), dim3(256), 0, st, src, ld_src, idx, out,
+                       ld_out, n_out, C / 4, accumulate);
+  } else {
+    hipLaunchKernelGGL(k_gather_rows<1>, dim3(hotk_grid(n_out * C, 256)), dim3(256), 0, st, src, ld_src, idx, out,
+                       ld_out, n_out, C, accumulate);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_mask_rows(const float* src, int64_t ld_src, const uint8_t* kind, unsigned keep, float fill,
+                              float* out, int64_t ld_out, int64_t n, int64_t C, void* stream) {
+  HOTK_CHECK_ARG(n >= 0 && C >= 0 && ld_src >= C && ld_out >= C);
+  if (n == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(src && out && kind);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(C, {ld_src, ld_out}, {src, out})) {
+    hipLaunchKernelGGL(k_mask_rows<4>, dim3(hotk_grid(n * (C / 4), 256)), dim3(256), 0, st, src, ld_src, kind, keep,
+                       fill, out, ld_out, n, C / 4);
+  } else {
+    hipLaunchKernelGGL(k_mask_rows<1>, dim3(hotk_grid(n * C, 256)), dim3(256), 0, st, src, ld_src, kind, keep, fill,
+                       out, ld_out, n, C);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t* seg_begin, const int32_t* seg_end,
+                                 const int32_t* perm, const uint8_t* kind, unsigned keep, float* out, int64_t ld_out,
+                                 int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream) {
+  HOTK_CHECK_ARG(n_seg >= 0 && C >= 0 && ld_src >= C && ld_out >= C && max_seg_len >= 0);
+  if (n_seg == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(src && out && seg_begin && seg_end);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t n_chunk = (max_seg_len + HOTK_SEG_CHUNK - 1) / HOTK_SEG_CHUNK;
+  if (n_chunk < 1) n_chunk = 1;
+  if (vec4_ok(C, {ld_src, ld_out}, {src, out})) {
+    hipLaunchKernelGGL(k_seg_sum_rows<4>, dim3(hotk_grid(n_seg * n_chunk * (C / 4), 256)), dim3(256), 0, st, src,
+                       ld_src, seg_begin, seg_end, perm, kind, keep, out, ld_out, n_seg, C / 4, n_chunk);
+  } else {
+    hipLaunchKernelGGL(k_seg_sum_rows<1>, dim3(hotk_grid(n_seg * n_chunk * C, 256)), dim3(256), 0, st, src, ld_src,
+                       seg_begin, seg_end, perm, kind, keep, out, ld_out, n_seg, C, n_chunk);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* b_off,
+                                   const float* b_diag, int64_t n, int64_t C, void* stream) {
+  HOTK_CHECK_ARG(n >= 0 && C >= 0 && ld >= C);
+  if (n == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(y && kind);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(C, {ld}, {y, b_off, b_diag})) {
+    hipLaunchKernelGGL(k_bias_mask_rows<4>, dim3(hotk_grid(n * (C / 4), 256)), dim3(256), 0, st, y, ld, kind, b_off,
+                       b_diag, n, C / 4);
+  } else {
+    hipLaunchKernelGGL(k_bias_mask_rows<1>, dim3(hotk_grid(n * C, 256)), dim3(256), 0, st, y, ld, kind, b_off, b_diag,
+                       n, C);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* kind, float* db_off, float* db_diag,
+                                   int64_t n, int64_t C, void* stream) {
+  HOTK_CHECK_ARG(n >= 0 && C >= 0 && ld >= C);
+  if (n == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(dy && kind);
+  hipStream_t st = (hipStream_t)stream;
+  int64_t blocks = hotk_grid(n, 64, 2048);  // >= 64 rows per block
+  int64_t rpb = (n + blocks - 1) / blocks;
+  blocks = (n + rpb - 1) / rpb;
+  hipLaunchKernelGGL(k_bias_grad_rows, dim3((unsigned)blocks), dim3(256), 0, st, dy, ld, kind, db_off, db_diag, n, C,
+                     rpb);
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_basis22_light_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* rown,
+                                      const int32_t* coln, const int32_t* tpos, const int32_t* diag_pos, float* x5,
+                                      int64_t ld_x5, int64_t R, int64_t D, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_x >= D && ld_x5 >= 5 * D);
+  if (R == 0 || D == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(x && kind && rown && coln && tpos && diag_pos && x5);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(D, {ld_x, ld_x5}, {x, x5})) {
+    hipLaunchKernelGGL(k_basis22_light_fwd<4>, dim3(hotk_grid(R * (D / 4), 256)), dim3(256), 0, st, x, ld_x, kind, rown,
+                       coln, tpos, diag_pos, x5, ld_x5, R, D);
+  } else {
+    hipLaunchKernelGGL(k_basis22_light_fwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, x, ld_x, kind, rown, coln,
+                       tpos, diag_pos, x5, ld_x5, R, D);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_basis22_light_bwd(const float* dx5, int64_t ld_dx5, const uint8_t* kind, const int32_t* rown,
+                                      const int32_t* tpos, const int32_t* row_ptr, const int32_t* row_perm,
+                                      const int32_t* col_ptr, const int32_t* col_perm, float* dx, int64_t ld_dx,
+                                      int64_t R, int64_t D, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_dx >= D && ld_dx5 >= 5 * D);
+  if (R == 0 || D == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(dx5 && kind && rown && tpos && row_ptr && row_perm && col_ptr && col_perm && dx);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(D, {ld_dx5, ld_dx}, {dx5, dx})) {
+    hipLaunchKernelGGL(k_basis22_light_bwd<4>, dim3(hotk_grid(R * (D / 4), 256)), dim3(256), 0, st, dx5, ld_dx5, kind,
+                       rown, tpos, row_ptr, row_perm, col_ptr, col_perm, dx, ld_dx, R, D);
+  } else {
+    hipLaunchKernelGGL(k_basis22_light_bwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, dx5, ld_dx5, kind, rown,
+                       tpos, row_ptr, row_perm, col_ptr, col_perm, dx, ld_dx, R, D);
+  }
+  return hotk_launch_status();
+}

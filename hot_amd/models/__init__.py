@@ -1,0 +1,2 @@
+from .encoder import Encoder, EncLayer  # noqa: F401
+from . import common, sparse  # noqa: F401

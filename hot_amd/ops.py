@@ -1,0 +1,315 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels of libhotk.so.
+
+Tensors are torch tensors (device memory, streams: plumbing); all arithmetic on the path happens in the HIP
+kernels.  Each wrapper states which reference code it stands in for.
+"""
+from ctypes import byref, c_size_t, c_float
+
+import torch
+from torch.autograd import Function
+
+from . import _lib
+from ._lib import lib, p, check, stream_ptr, rows2d, KEEP_DIAG, KEEP_OFFDIAG, KEEP_VALID, SEG_CHUNK
+
+
+# ------------------------------------------------------------------------------------------------
+# raw launchers (no autograd)
+# ------------------------------------------------------------------------------------------------
+def gather_rows(src, idx, n_out, out=None, accumulate=False):
+    s, ld, n, C = rows2d(src)
+    if out is None:
+        out = torch.empty(n_out, C, dtype=src.dtype, device=src.device)
+    o, ldo, no, Co = rows2d(out)
+    assert o.data_ptr() == out.data_ptr() and no == n_out and Co == C
+    check(lib().hotk_gather_rows(p(s), ld, p(idx), p(o), ldo, n_out, C, int(accumulate), stream_ptr()), 'hotk_gather_rows')
+    return out
+
+
+def mask_rows(src, kind, keep, fill=0.0):
+    s, ld, n, C = rows2d(src)
+    assert kind.numel() == n, (kind.numel(), n)
+    out = torch.empty(src.shape, dtype=src.dtype, device=src.device)
+    check(lib().hotk_mask_rows(p(s), ld, p(kind), keep, c_float(fill), p(out), C, n, C, stream_ptr()), 'hotk_mask_rows')
+    return out
+
+
+def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID):
+    beg, end, perm, maxlen = seg
+    s, ld, n, C = rows2d(src)
+    n_seg = beg.numel()
+    alloc = torch.zeros if maxlen > SEG_CHUNK else torch.empty
+    out = alloc(n_seg, C, dtype=src.dtype, device=src.device)
+    check(lib().hotk_seg_sum_rows(p(s), ld, p(beg), p(end), p(perm), p(kind), keep, p(out), C, n_seg, C, maxlen,
+                                  stream_ptr()), 'hotk_seg_sum_rows')
+    return out
+
+
+def seg_outer_sum(K, kidx, V, vidx, aug, seg, HH, m, c):
+    beg, end, perm, maxlen = seg
+    k, ldk, _, Ck = rows2d(K)
+    v, ldv, _, Cv = rows2d(V)
+    assert Ck == HH * m and Cv == HH * c, (Ck, Cv, HH, m, c)
+    if aug is not None:
+        a, lda, _, Ca = rows2d(aug)
+        assert Ca == HH
+    else:
+        a, lda = None, 0
+    n_seg = beg.numel()
+    alloc = torch.zeros if maxlen > SEG_CHUNK else torch.empty
+    KV = alloc(n_seg, HH * m, c + 1, dtype=K.dtype, device=K.device)
+    check(lib().hotk_seg_outer_sum(p(k), ldk, p(kidx), p(v), ldv, p(vidx), p(a), lda, p(beg), p(end), p(perm), p(KV),
+                                   n_seg, HH, m, c, maxlen, stream_ptr()), 'hotk_seg_outer_sum')
+    return KV
+
+
+def row_contract(Q, qidx, KV, sidx, seg_div, kind, keep, n, HH, m, c, normalize, oidx=None, n_out=None):
+    q, ldq, _, Cq = rows2d(Q)
+    assert Cq == HH * m
+    n_out = n if n_out is None else n_out
+    alloc = torch.zeros if oidx is not None else torch.empty
+    out = alloc(n_out, HH * c, dtype=Q.dtype, device=Q.device)
+    check(lib().hotk_row_contract(p(q), ldq, p(qidx), p(KV), p(sidx), seg_div, p(kind), keep, p(oidx), p(out), HH * c, n,
+                                  HH, m, c, int(normalize), stream_ptr()), 'hotk_row_contract')
+    return out
+
+
+def apply_bwd_stats(Q, KV, sidx, seg_div, kind, keep, dO, n, HH, m, c):
+    q, ldq, _, _ = rows2d(Q)
+    g, ldg, ng, Cg = rows2d(dO)
+    assert ng == n and Cg == HH * c
+    X = torch.empty(n, HH * c, dtype=Q.dtype, device=Q.device)
+    XA = torch.empty(n, HH, dtype=Q.dtype, device=Q.device)
+    check(lib().hotk_apply_bwd_stats(p(q), ldq, p(KV), p(sidx), seg_div, p(kind), keep, p(g), ldg, p(X), HH * c, p(XA), HH,
+                                     n, HH, m, c, stream_ptr()), 'hotk_apply_bwd_stats')
+    return X, XA
+
+
+def row_expand(KV, sidx, seg_div, X, xidx, XA, kind, keep, n, HH, m, c):
+    x, ldx, _, Cx = rows2d(X)
+    assert Cx == HH * c
+    if XA is not None:
+        a, lda, _, _ = rows2d(XA)
+    else:
+        a, lda = None, 0
+    out = torch.empty(n, HH * m, dtype=X.dtype, device=X.device)
+    check(lib().hotk_row_expand(p(KV), p(sidx), seg_div, p(x), ldx, p(xidx), p(a), lda, p(kind), keep, p(out), HH * m, n,
+                                HH, m, c, stream_ptr()), 'hotk_row_expand')
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# autograd functions
+# ------------------------------------------------------------------------------------------------
+class GatherRows(Function):
+    """out[r] = src[idx[r]] (zeros where idx < 0); idx_bwd is the inverse map (the maps used on this path
+    are injective: transpose positions, diagonal positions).
+    Stands in for do_transpose / get_diag / to_diag (hot_pytorch/utils/sparse.py:34-87,130-134)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, idx_bwd, n_out):
+        ctx.save_for_backward(idx_bwd)
+        ctx.n_src = src.numel() // src.size(-1)
+        ctx.src_shape = src.shape
+        return gather_rows(src, idx, n_out)
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx_bwd,) = ctx.saved_tensors
+        d = gather_rows(g.contiguous(), idx_bwd, ctx.n_src)
+        return d.view(ctx.src_shape), None, None, None
+
+
+class MaskRows(Function):
+    """Zero the rows whose kind is not kept.  Stands in for masked_fill / apply_mask / get_nondiag
+    (utils/set.py:47-48, batch/sparse.py:77-80, utils/sparse.py:90-99)."""
+
+    @staticmethod
+    def forward(ctx, src, kind, keep, fill):
+        ctx.save_for_backward(kind)
+        ctx.keep = keep
+        return mask_rows(src, kind, keep, fill)
+
+    @staticmethod
+    def backward(ctx, g):
+        (kind,) = ctx.saved_tensors
+        return mask_rows(g, kind, ctx.keep, 0.0), None, None, None
+
+
+class SegSumRows(Function):
+    """out[s] = sum of the rows of segment s (row kinds filtered); backward broadcasts the segment gradient
+    back to its rows through `row_seg` (segment id per row, -1 = none)."""
+
+    @staticmethod
+    def forward(ctx, src, seg, kind, keep, row_seg):
+        ctx.save_for_backward(kind, row_seg)
+        ctx.keep = keep
+        ctx.src_shape = src.shape
+        return seg_sum_rows(src, seg, kind, keep)
+
+    @staticmethod
+    def backward(ctx, g):
+        kind, row_seg = ctx.saved_tensors
+        n = row_seg.numel()
+        d = gather_rows(g.contiguous(), row_seg, n)
+        if kind is not None:
+            d = mask_rows(d, kind, ctx.keep, 0.0)
+        return d.view(ctx.src_shape), None, None, None, None
+
+
+class Phi(Function):
+    """Fused FAVOR+ feature map: head split -> projection -> ReLU/exp -> loop + padding masks.
+    Stands in for KernelFeatureMapWrapper.forward (models/sparse/kernelattncoef.py:19-28) and
+    KernelFeatureMap.{generalized_map,softmax_map} (models/common/kernel.py:81-138)."""
+
+    @staticmethod
+    def forward(ctx, x, proj, kind, keep, d, mode):
+        xs, ld, n, C = rows2d(x)
+        m = proj.size(0)
+        assert proj.size(1) == d and C % d == 0
+        HH = C // d
+        proj = proj.contiguous().float()
+        gstat = None
+        if mode == _lib.PHI_SOFTMAX_K:
+            gstat = torch.zeros(4, dtype=torch.float32, device=x.device)
+            need = c_size_t(0)
+            check(lib().hotk_phi_stats_workspace_bytes(n, HH, m, byref(need)), 'hotk_phi_stats_workspace_bytes')
+            ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
+            check(lib().hotk_phi_key_stats(p(xs), ld, p(proj), n, HH, d, m, p(gstat), p(ws), need.value, stream_ptr()),
+                  'hotk_phi_key_stats')
+        out = torch.empty(*x.shape[:-1], HH * m, dtype=x.dtype, device=x.device)
+        check(lib().hotk_phi_fwd(p(xs), ld, p(proj), p(kind), keep, p(out), HH * m, n, HH, d, m, mode, p(gstat),
+                                 stream_ptr()), 'hotk_phi_fwd')
+        ctx.save_for_backward(xs, proj, kind, gstat)
+        ctx.cfg = (ld, n, HH, d, m, mode, keep, x.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, proj, kind, gstat = ctx.saved_tensors
+        ld, n, HH, d, m, mode, keep, xshape = ctx.cfg
+        gs, ldg, ng, Cg = rows2d(g)
+        assert ng == n and Cg == HH * m
+        if mode == _lib.PHI_SOFTMAX_K:
+            gstat = gstat.clone()
+            need = c_size_t(0)
+            check(lib().hotk_phi_stats_workspace_bytes(n, HH, m, byref(need)), 'hotk_phi_stats_workspace_bytes')
+            ws = torch.empty(need.value, dtype=torch.uint8, device=g.device)
+            check(lib().hotk_phi_key_bwd_stats(p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, n, HH, d, m, p(gstat),
+                                               p(ws), need.value, stream_ptr()), 'hotk_phi_key_bwd_stats')
+        dx = torch.empty(xshape, dtype=g.dtype, device=g.device)
+        check(lib().hotk_phi_bwd(p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, p(dx), HH * d, n, HH, d, m, mode,
+                                 p(gstat), stream_ptr()), 'hotk_phi_bwd')
+        return dx, None, None, None, None, None
+
+
+class Basis22Light(Function):
+    """[R,D] -> [R,5D] order-2 'light' basis (models/sparse/linear.py:143-161)."""
+
+    @staticmethod
+    def forward(ctx, x, plan):
+        xs, ld, n, D = rows2d(x)
+        assert n == plan.R
+        out = torch.empty(*x.shape[:-1], 5 * D, dtype=x.dtype, device=x.device)
+        check(lib().hotk_basis22_light_fwd(p(xs), ld, p(plan.kind), p(plan.rown), p(plan.coln), p(plan.tpos),
+                                           p(plan.diag_pos), p(out), 5 * D, n, D, stream_ptr()), 'hotk_basis22_light_fwd')
+        ctx.plan = plan
+        ctx.xshape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        plan = ctx.plan
+        gs, ldg, n, C5 = rows2d(g)
+        D = C5 // 5
+        dx = torch.empty(ctx.xshape, dtype=g.dtype, device=g.device)
+        check(lib().hotk_basis22_light_bwd(p(gs), ldg, p(plan.kind), p(plan.rown), p(plan.tpos), p(plan.row_ptr),
+                                           p(plan.row_perm), p(plan.col_ptr), p(plan.col_perm), p(dx), D, n, D,
+                                           stream_ptr()), 'hotk_basis22_light_bwd')
+        return dx, None
+
+
+class BiasMask(Function):
+    """y + bias by row kind, padding rows zeroed, in place on y (a fresh GEMM output).
+    Stands in for _Bias._1/_2 followed by Linear's apply_mask(0) (models/sparse/linear.py:293-306,345-346)."""
+
+    @staticmethod
+    def forward(ctx, y, kind, b_off, b_diag):
+        ys, ld, n, C = rows2d(y)
+        assert ys.data_ptr() == y.data_ptr(), 'BiasMask expects a row-contiguous tensor'
+        check(lib().hotk_bias_mask_rows(p(ys), ld, p(kind), p(b_off), p(b_diag), n, C, stream_ptr()), 'hotk_bias_mask_rows')
+        ctx.mark_dirty(y)
+        ctx.save_for_backward(kind)
+        ctx.has = (b_off is not None, b_diag is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        (kind,) = ctx.saved_tensors
+        gs, ld, n, C = rows2d(g)
+        db_off = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[0] else None
+        db_diag = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[1] else None
+        if db_off is not None or db_diag is not None:
+            check(lib().hotk_bias_grad_rows(p(gs), ld, p(kind), p(db_off), p(db_diag), n, C, stream_ptr()),
+                  'hotk_bias_grad_rows')
+        return mask_rows(g, kind, KEEP_VALID, 0.0), None, db_off, db_diag
+
+
+class KernelAttn(Function):
+    """Key-value-first kernel attention for one (already channel-concatenated) query/key/value triple.
+    Stands in for KernelAttnCoef.forward (models/sparse/kernelattncoef.py:198-234): per-graph sums when
+    diagonal is None, per-column sums (keys gathered by row node) otherwise; the output is zero on padding
+    and, for order-2 queries, on diagonal rows.  KV is recomputed nowhere: it is saved for the backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, plan, ord_q, ord_k, m, c, diagonal):
+        HH = q.size(-1) // m
+        assert q.size(-1) == HH * m and k.size(-1) == HH * m and v.size(-1) == HH * c, (q.shape, k.shape, v.shape, m, c)
+        nq = q.numel() // q.size(-1)
+        nk = k.numel() // k.size(-1)
+        nv = v.numel() // v.size(-1)
+        if diagonal is None:
+            assert nk == nv
+            seg = plan.graph_seg(ord_k)
+            kidx = None
+            sidx, seg_div = None, (plan.Nmax if ord_q == 1 else plan.Emax)
+            vsidx, vseg_div = None, (plan.Nmax if ord_k == 1 else plan.Emax)
+        else:
+            dim1 = diagonal[0]
+            assert ord_k == 1 and nv == plan.R and nk == plan.Nn
+            seg = plan.col_seg()
+            kidx = plan.rown
+            if ord_q == 1:
+                sidx, seg_div = None, 1
+            else:
+                sidx, seg_div = (plan.coln if dim1 == 2 else plan.rown), 1
+            vsidx, vseg_div = plan.coln, 1
+        kind_q, keep_q = (plan.nkind, KEEP_DIAG) if ord_q == 1 else (plan.kind, KEEP_OFFDIAG)
+        KV = seg_outer_sum(k, kidx, v, None, None, seg, HH, m, c)
+        out = row_contract(q, None, KV, sidx, seg_div, kind_q, keep_q, nq, HH, m, c, True)
+        ctx.save_for_backward(q, k, v, KV)
+        ctx.cfg = (plan, ord_q, ord_k, HH, m, c, diagonal, nq, nk, nv, kidx, sidx, seg_div, vsidx, vseg_div, kind_q, keep_q)
+        return out.view(*q.shape[:-1], HH * c)
+
+    @staticmethod
+    def backward(ctx, dO):
+        q, k, v, KV = ctx.saved_tensors
+        plan, ord_q, ord_k, HH, m, c, diagonal, nq, nk, nv, kidx, sidx, seg_div, vsidx, vseg_div, kind_q, keep_q = ctx.cfg
+        dO = dO.contiguous()
+        X, XA = apply_bwd_stats(q, KV, sidx, seg_div, kind_q, keep_q, dO, nq, HH, m, c)
+        dq = row_expand(KV, sidx, seg_div, X, None, XA, kind_q, keep_q, nq, HH, m, c)
+        # dKV[s] = sum over the queries that read segment s of q (x) [dnum | dden]
+        if diagonal is None:
+            qseg = plan.graph_seg(ord_q)
+        elif ord_q == 1:
+            qseg = plan.unit_seg(nq)
+        else:
+            qseg = plan.col_seg() if diagonal[0] == 2 else plan.row_seg()
+        dKV = seg_outer_sum(q, None, X, None, XA, qseg, HH, m, c)
+        kind_v = plan.nkind if (diagonal is None and ord_k == 1) else plan.kind
+        dv = row_contract(k, kidx, dKV, vsidx, vseg_div, kind_v, KEEP_VALID, nv, HH, m, c, False)
+        dkc = row_expand(dKV, vsidx, vseg_div, v, None, None, kind_v, KEEP_VALID, nv, HH, m, c)
+        if diagonal is None:
+            dk = dkc
+        else:
+            dk = seg_sum_rows(dkc, plan.row_seg())
+        return dq.view(q.shape), dk.view(k.shape), dv.view(v.shape), None, None, None, None, None, None

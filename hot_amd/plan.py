@@ -1,0 +1,125 @@
+"""Segment plan of a padded order-2 batch: everything index-shaped that the kernels need, built once per
+minibatch on the device by hotk_plan_build (K1) and shared by every Batch that re-wraps the same indices.
+
+Replaces get_transpose_info (hot_pytorch/utils/sparse.py:102-127) and the per-call index arithmetic of
+models/sparse/kernelattncoef.py:105-122,145-157 (node offsets, boolean-mask compaction, coalesce sort).
+"""
+from ctypes import byref, c_size_t
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, p, check, stream_ptr
+
+
+class Plan:
+    """int32 device arrays over padded rows: R = B*Emax entry rows, Nn = B*Nmax node rows."""
+
+    def __init__(self, indices: torch.Tensor, n_nodes, n_entries):
+        _lib.require_device(indices, 'indices')
+        assert indices.dtype == torch.long and indices.dim() == 3 and indices.size(-1) == 2
+        dev = indices.device
+        indices = indices.contiguous()
+        B, Emax = indices.size(0), indices.size(1)
+        n_nodes = [int(x) for x in n_nodes]
+        n_entries = [int(x) for x in n_entries]
+        assert len(n_nodes) == B and len(n_entries) == B
+        Nmax = max(n_nodes) if B else 0
+        assert max(n_entries, default=0) <= Emax
+        self.B, self.Emax, self.Nmax = B, Emax, Nmax
+        self.R, self.Nn = B * Emax, B * Nmax
+        self.Ev = int(sum(n_entries))
+        nn = np.asarray(n_nodes, dtype=np.int32)
+        ne = np.asarray(n_entries, dtype=np.int32)
+        eofs = np.concatenate([[0], np.cumsum(ne[:-1], dtype=np.int64)]).astype(np.int64) if B else np.zeros(0, np.int64)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.n_nodes_dev = torch.from_numpy(nn).to(dev)
+        self.n_entries_dev = torch.from_numpy(ne).to(dev)
+        entry_ofs = torch.from_numpy(eofs).to(dev)
+        # graph segments in padded row numbering (padding excluded)
+        eb = np.arange(B, dtype=np.int64) * Emax
+        nb = np.arange(B, dtype=np.int64) * Nmax
+        self.g_ebeg = torch.from_numpy(eb.astype(np.int32)).to(dev)
+        self.g_eend = torch.from_numpy((eb + ne).astype(np.int32)).to(dev)
+        self.g_nbeg = torch.from_numpy(nb.astype(np.int32)).to(dev)
+        self.g_nend = torch.from_numpy((nb + nn).astype(np.int32)).to(dev)
+        self.iota = torch.arange(max(self.R, self.Nn) + 1, **i32)
+        R, Nn, Ev = self.R, self.Nn, self.Ev
+        self.t_indices = torch.empty(B, Emax, dtype=torch.long, device=dev)
+        self.t_mask = torch.empty(B, Emax, dtype=torch.bool, device=dev)
+        self.rown = torch.empty(R, **i32)
+        self.coln = torch.empty(R, **i32)
+        self.kind = torch.empty(R, dtype=torch.uint8, device=dev)
+        self.tpos = torch.empty(R, **i32)
+        self.diag_pos = torch.empty(Nn, **i32)
+        self.nkind = torch.empty(Nn, dtype=torch.uint8, device=dev)
+        self.col_ptr = torch.empty(Nn + 1, **i32)
+        self.row_ptr = torch.empty(Nn + 1, **i32)
+        self.col_perm = torch.empty(max(Ev, 1), **i32)
+        self.row_perm = torch.empty(max(Ev, 1), **i32)
+        status = torch.empty(4, **i32)
+        need = c_size_t(0)
+        check(lib().hotk_plan_workspace_bytes(B, Emax, Nmax, Ev, byref(need)), 'hotk_plan_workspace_bytes')
+        ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev)
+        check(lib().hotk_plan_build(p(indices), p(self.n_nodes_dev), p(self.n_entries_dev), p(entry_ofs), B, Emax, Nmax,
+                                    Ev, p(self.t_indices), p(self.t_mask), p(self.rown), p(self.coln), p(self.kind),
+                                    p(self.tpos), p(self.diag_pos), p(self.nkind), p(self.col_ptr), p(self.col_perm),
+                                    p(self.row_ptr), p(self.row_perm), p(status), p(ws), need.value, stream_ptr()),
+              'hotk_plan_build')
+        st = status.cpu().tolist()   # one host sync per minibatch: sizes of the long-segment split + validation
+        del ws
+        if st[1]:
+            raise ValueError('sparse Batch: an index of a valid entry is outside [0, n_nodes) of its graph')
+        if st[0]:
+            raise ValueError('sparse Batch: layout invariant broken - each graph must list its n diagonal entries '
+                             '(v,v) first and in order, followed by off-diagonal entries only '
+                             '(hot_pytorch/batch/sparse.py:38)')
+        self.max_col_deg, self.max_row_deg = int(st[2]), int(st[3])
+        # node row of a diagonal entry (-1 elsewhere): inverse of diag_pos, derived on the device
+        self.diag_node = torch.where(self.kind == 1, self.rown, torch.full_like(self.rown, -1))
+        self.device = dev
+
+    # CSR views ---------------------------------------------------------------------------------
+    def col_seg(self):
+        return self.col_ptr[:-1], self.col_ptr[1:], self.col_perm, self.max_col_deg
+
+    def row_seg(self):
+        return self.row_ptr[:-1], self.row_ptr[1:], self.row_perm, self.max_row_deg
+
+    def graph_seg(self, order):
+        if order == 1:
+            return self.g_nbeg, self.g_nend, None, self.Nmax
+        return self.g_ebeg, self.g_eend, None, self.Emax
+
+    def unit_seg(self, n):
+        return self.iota[:n], self.iota[1:n + 1], None, 1
+
+
+def node_plan(n_nodes, device, Nmax=None):
+    """Order-1 batches built without an order-2 parent only need node kinds and graph ranges."""
+    return NodePlan(n_nodes, device, Nmax)
+
+
+class NodePlan:
+    def __init__(self, n_nodes, device, Nmax=None):
+        n_nodes = [int(x) for x in n_nodes]
+        B = len(n_nodes)
+        Nmax = (max(n_nodes) if B else 0) if Nmax is None else Nmax
+        self.B, self.Nmax, self.Nn = B, Nmax, B * Nmax
+        self.Emax, self.R = 0, 0
+        nn = np.asarray(n_nodes, dtype=np.int64)
+        nb = np.arange(B, dtype=np.int64) * Nmax
+        self.g_nbeg = torch.from_numpy(nb.astype(np.int32)).to(device)
+        self.g_nend = torch.from_numpy((nb + nn).astype(np.int32)).to(device)
+        valid = (np.arange(Nmax)[None, :] < nn[:, None]).reshape(-1).astype(np.uint8)
+        self.nkind = torch.from_numpy(valid).to(device)
+        self.iota = torch.arange(self.Nn + 1, dtype=torch.int32, device=device)
+        self.device = device
+
+    def graph_seg(self, order):
+        assert order == 1
+        return self.g_nbeg, self.g_nend, None, self.Nmax
+
+    def unit_seg(self, n):
+        return self.iota[:n], self.iota[1:n + 1], None, 1

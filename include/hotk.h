@@ -1,0 +1,169 @@
+/*
+ * hotk.h -- C ABI of libhotk.so: hand-written gfx950 (MI355X) HIP kernels for the second-order sparse
+ * kernel-attention path of Higher-Order Transformers (reference: jw9730/hot, pure PyTorch; the reference
+ * has no FFI of its own, so every entry point cites the reference Python it replaces, file:line relative
+ * to the reference checkout).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (contiguous, 4-byte aligned; 16-byte alignment
+ *     enables the vector paths); nothing here allocates, frees or synchronises;
+ *   - `stream` is a hipStream_t passed as void*; kernels are enqueued on it and the call returns;
+ *   - return value: HOTK_OK (0) or a negative HOTK_E* code; hotk_strerror() names it;
+ *   - "rows": order-2 tensors are [R = B*Emax, C] (padded entry rows), order-1 tensors are
+ *     [Nn = B*Nmax, C] (padded node rows); `ld*` is the row stride in floats, so a column slice of a wider
+ *     tensor is passed as (ptr + col0, ld) without a copy;
+ *   - kind[r] (uint8): 0 = padding, 1 = diagonal entry / valid node, 2 = off-diagonal entry;
+ *     `keep` is a bit set over kinds (bit k set = rows of kind k pass, others are written as zero).
+ */
+#ifndef HOTK_H
+#define HOTK_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HOTK_OK 0
+#define HOTK_EINVAL (-1)   /* null pointer / bad size / bad mode          */
+#define HOTK_EWORKSPACE (-2) /* workspace too small                        */
+#define HOTK_ELAUNCH (-3)  /* hipLaunch / runtime error                    */
+#define HOTK_EUNSUPPORTED (-4)
+
+#define HOTK_KEEP_PAD 1u
+#define HOTK_KEEP_DIAG 2u
+#define HOTK_KEEP_OFFDIAG 4u
+
+const char* hotk_strerror(int code);
+int hotk_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * K1  edge-index sort / segment construction
+ * replaces hot_pytorch/utils/sparse.py:102-127 (get_transpose_info, O(E^2) all-pairs match) and the
+ * implicit grouping done by torch.sparse coalesce() in models/sparse/kernelattncoef.py:103-122.
+ *
+ * in : indices [B,Emax,2] int64 (local node ids, padding rows (0,0)); n_nodes[B], n_entries[B]
+ *      (= n_b + e_b) int32; entry_ofs[B] int64 = exclusive cumsum of n_entries; Ev = sum(n_entries)
+ * out: t_indices [B,Emax] int64, t_mask [B,Emax] bool -- bit-exact with the reference;
+ *      rown/coln [R] int32 padded node row of i / j (-1 on padding), kind [R] uint8,
+ *      tpos [R] int32 padded entry row of the transposed entry (-1 if none),
+ *      diag_pos [Nn] int32 entry row of node's diagonal (-1 on padded nodes), nkind [Nn] uint8,
+ *      col_ptr/row_ptr [Nn+1], col_perm/row_perm [Ev] int32: entries grouped by column / row node,
+ *      column groups ordered by entry row, row groups ordered by (column node, entry row);
+ *      status [4] int32: [0] diagonal-prefix layout invariant broken (batch/sparse.py:38),
+ *      [1] index out of range, [2] max column degree, [3] max row degree.
+ * ---------------------------------------------------------------------------------------------- */
+int hotk_plan_workspace_bytes(int64_t B, int64_t Emax, int64_t Nmax, int64_t Ev, size_t* bytes);
+int hotk_plan_build(const int64_t* indices, const int32_t* n_nodes, const int32_t* n_entries,
+                    const int64_t* entry_ofs, int64_t B, int64_t Emax, int64_t Nmax, int64_t Ev,
+                    int64_t* t_indices, uint8_t* t_mask, int32_t* rown, int32_t* coln, uint8_t* kind,
+                    int32_t* tpos, int32_t* diag_pos, uint8_t* nkind, int32_t* col_ptr, int32_t* col_perm,
+                    int32_t* row_ptr, int32_t* row_perm, int32_t* status, void* workspace, size_t ws_bytes,
+                    void* stream);
+/* stable LSD radix sort of (key,value) uint32 pairs on the low `bits` bits of key; used by the plan and
+ * exported for tests.  workspace: hotk_sort_workspace_bytes(n). keys/vals are sorted in place. */
+int hotk_sort_workspace_bytes(int64_t n, size_t* bytes);
+int hotk_sort_pairs_u32(uint32_t* keys, uint32_t* vals, int64_t n, int bits, void* workspace, size_t ws_bytes,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  coalesced row gather / mask / segment sums
+ * ---------------------------------------------------------------------------------------------- */
+/* out[r] = idx[r] >= 0 ? src[idx[r]] : 0   (idx NULL = identity); accumulate != 0 adds into out.
+ * replaces do_transpose (utils/sparse.py:130-134), get_diag / to_diag (utils/sparse.py:34-87) and their
+ * autograd mirrors. */
+int hotk_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, float* out, int64_t ld_out,
+                     int64_t n_out, int64_t C, int accumulate, void* stream);
+/* out[r] = (keep >> kind[r]) & 1 ? src[r] : fill.  replaces masked_fill (utils/set.py:47-48), get_nondiag
+ * (utils/sparse.py:90-99), Batch.apply_mask (batch/sparse.py:77-80). */
+int hotk_mask_rows(const float* src, int64_t ld_src, const uint8_t* kind, unsigned keep, float fill,
+                   float* out, int64_t ld_out, int64_t n, int64_t C, void* stream);
+/* out[s] = sum over p in [seg_begin[s], seg_end[s]) of src[perm[p]] restricted to kinds in `keep`
+ * (perm NULL = identity, kind NULL = no filter).  `out` must be zero-filled by the caller when
+ * max_seg_len > HOTK_SEG_CHUNK (long segments are split and combined with float atomics).
+ * replaces the M.float().bmm(values) poolings of models/sparse/linear.py:187-231 and scatter_add_
+ * backward of the gathers. */
+#define HOTK_SEG_CHUNK 1024
+int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t* seg_begin, const int32_t* seg_end,
+                      const int32_t* perm, const uint8_t* kind, unsigned keep, float* out, int64_t ld_out,
+                      int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream);
+/* y[r] = kind 2: y + b_off, kind 1: y + b_diag, kind 0: 0   (in place).  order-2 _Bias + apply_mask
+ * (models/sparse/linear.py:297-306,345-346); order 1: pass nkind and b_diag (b_off may be NULL). */
+int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* b_off, const float* b_diag,
+                        int64_t n, int64_t C, void* stream);
+/* db_off[c] = sum over kind-2 rows of dy, db_diag[c] = sum over kind-1 rows; outputs must be zeroed. */
+int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* kind, float* db_off, float* db_diag,
+                        int64_t n, int64_t C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K4  order-2 equivariant basis, 'light' configuration (models/sparse/linear.py:143-161):
+ * X5[r] = [ diag? x_r | off? x_r | off&tau? x_t(r) | off? x_(i,i) | off? x_(j,j) ]   ([R, 5*D])
+ * and its transpose (gradient) map.
+ * ---------------------------------------------------------------------------------------------- */
+int hotk_basis22_light_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* rown,
+                           const int32_t* coln, const int32_t* tpos, const int32_t* diag_pos, float* x5,
+                           int64_t ld_x5, int64_t R, int64_t D, void* stream);
+int hotk_basis22_light_bwd(const float* dx5, int64_t ld_dx5, const uint8_t* kind, const int32_t* rown,
+                           const int32_t* tpos, const int32_t* row_ptr, const int32_t* row_perm,
+                           const int32_t* col_ptr, const int32_t* col_perm, float* dx, int64_t ld_dx,
+                           int64_t R, int64_t D, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K2  FAVOR+ random-feature maps (models/common/kernel.py:81-138 fused with the head split, loop mask
+ * and padding mask of models/sparse/kernelattncoef.py:19-28).
+ * x [n, HH*d] -> phi [n, HH*m]; proj [m,d].  mode: 0 generalized ReLU (+1e-3), 1 softmax query,
+ * 2 softmax key (needs gstat from hotk_phi_key_stats).  Rows whose kind is not in `keep` are zero.
+ * ---------------------------------------------------------------------------------------------- */
+#define HOTK_PHI_RELU 0
+#define HOTK_PHI_SOFTMAX_Q 1
+#define HOTK_PHI_SOFTMAX_K 2
+int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind, unsigned keep,
+                 float* phi, int64_t ld_phi, int64_t n, int HH, int d, int m, int mode, const float* gstat,
+                 void* stream);
+int hotk_phi_bwd(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind, unsigned keep,
+                 const float* dphi, int64_t ld_dphi, float* dx, int64_t ld_dx, int64_t n, int HH, int d,
+                 int m, int mode, const float* gstat, void* stream);
+/* gstat[0] = max over ALL n rows (padding included, as the reference does, kernel.py:112) and heads of the
+ * projected data; workspace >= hotk_phi_stats_workspace_bytes(n, HH, m). */
+int hotk_phi_stats_workspace_bytes(int64_t n, int HH, int m, size_t* bytes);
+int hotk_phi_key_stats(const float* x, int64_t ld_x, const float* proj, int64_t n, int HH, int d, int m,
+                       float* gstat, void* workspace, size_t ws_bytes, void* stream);
+/* gstat[1] = sum over rows in keep of dphi * ratio * exp(.) (d loss / d(-max)), gstat[2] = number of
+ * elements equal to the max; needed by the key-branch backward. */
+int hotk_phi_key_bwd_stats(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind, unsigned keep,
+                           const float* dphi, int64_t ld_dphi, int64_t n, int HH, int d, int m, float* gstat,
+                           void* workspace, size_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * K3  segmented key-value reductions and their application
+ * (models/sparse/kernelattncoef.py:74-91 full / :103-122 partial sums, :124-175 query application).
+ * F = HH*m features, c = value channels per head; KV is [n_seg, F, c+1]: channels 0..c-1 hold
+ * sum phiK (x) V, channel c holds sum phiK * aug (aug = 1 in the forward pass: the normaliser).
+ * ---------------------------------------------------------------------------------------------- */
+/* KV[s][f][ch] = sum_{p in seg s} K[kidx[e]][f] * (ch<c ? V[vidx[e]][hh*c+ch] : AUG[e][hh] or 1), e = perm[p].
+ * kidx/vidx/perm NULL = identity; vidx[e] < 0 contributes zeros to the value channels only.
+ * KV must be zero-filled when max_seg_len > HOTK_SEG_CHUNK. */
+int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* kidx, const float* V, int64_t ld_v,
+                       const int32_t* vidx, const float* aug, int64_t ld_aug, const int32_t* seg_begin,
+                       const int32_t* seg_end, const int32_t* perm, float* KV, int64_t n_seg, int HH, int m,
+                       int c, int64_t max_seg_len, void* stream);
+/* out[orow][hh*c+ch] = sum_mm Q[qidx[r]][hh*m+mm] * KV[s][hh*m+mm][ch]  (/ guard(sum_mm Q*KV[..][c]) if
+ * normalize), s = sidx ? sidx[r] : r / seg_div, orow = oidx ? oidx[r] : r.  Rows with kind not in keep or
+ * s < 0 write zeros (skipped when oidx is given and orow < 0). */
+int hotk_row_contract(const float* Q, int64_t ld_q, const int32_t* qidx, const float* KV, const int32_t* sidx,
+                      int64_t seg_div, const uint8_t* kind, unsigned keep, const int32_t* oidx, float* out,
+                      int64_t ld_out, int64_t n, int HH, int m, int c, int normalize, void* stream);
+/* backward statistics of the normalised application: X[r][hh*c+ch] = dO/den, XA[r][hh] = -(dO.O)/den
+ * (0 where the 1e-5 guard was taken or the row is masked). */
+int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* KV, const int32_t* sidx, int64_t seg_div,
+                         const uint8_t* kind, unsigned keep, const float* dO, int64_t ld_do, float* X,
+                         int64_t ld_x, float* XA, int64_t ld_xa, int64_t n, int HH, int m, int c, void* stream);
+/* out[r][f] = sum_ch KV[s][f][ch] * X[xidx[r]][hh*c+ch] + KV[s][f][c] * (XA ? XA[r][hh] : 1) */
+int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const float* X, int64_t ld_x,
+                    const int32_t* xidx, const float* XA, int64_t ld_xa, const uint8_t* kind, unsigned keep,
+                    float* out, int64_t ld_out, int64_t n, int HH, int m, int c, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HOTK_H */
