@@ -1,0 +1,206 @@
+"""Headline benchmark: entries/s forward+backward of the 2->2 sparse kernel-attention layer (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload "S1/C1" (SURVEY 8d): B Barabasi-Albert(64, 5) graphs -> 654 entries each (64 diagonal + 590 directed
+edges), ~10 M entries per GPU; layer KernelSelfAttn(2,2, dim_in=32, dim_v=32, dim_qk=32, n_heads=4) with the
+generalized (ReLU) FAVOR+ map (d=8, m=16), fp32, dropout 0, fixed projection.  One step = layer(G) followed by
+out.values.sum().backward() (run_perf_tests.py:62-88), inputs resident in HBM.  Graph structures come from an own
+seeded BA generator (512 distinct graphs, tiled), features are seeded Gaussians generated on the device.
+Multi-GPU: graphs are independent, so every rank runs its own B graphs (weak scaling) and the parameter
+gradients are all-reduced over RCCL each step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # B/s, MI355X_MICROARCH.md chip table
+N_NODES, BA_M, ENTRIES_PER_GRAPH = 64, 5, 654
+D, DQK, DV, HEADS = 32, 32, 32, 4
+# algorithmic bytes of the attention core per entry, forward + backward: 96*dqk + 224*dv + 50, plus the
+# per-node term 2*4*12*dqk + 3*2*2*4*S*H*m*(dvh+1) (S=2, H=4, m=16, dvh=8) amortised over entries/node
+BYTES_PER_ENTRY = 96 * DQK + 224 * DV + 50
+BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEADS + 1)
+
+
+def build_structure(n_graphs, distinct=512, seed=1234):
+    """edge_index [2, n_graphs*590] (local ids) from `distinct` seeded BA graphs, tiled"""
+    from oracle.hot_oracle import ba_edges   # generator only (shared with the tests); no compute is routed here
+    rng = np.random.default_rng(seed)
+    base = [ba_edges(N_NODES, BA_M, rng) for _ in range(min(distinct, n_graphs))]
+    reps = (n_graphs + len(base) - 1) // len(base)
+    ei = np.concatenate((base * reps)[:n_graphs], axis=1)
+    return ei
+
+
+def make_inputs(n_graphs, device, seed):
+    from hot_amd.batch.sparse import make_batch_concatenated
+    ei = torch.from_numpy(build_structure(n_graphs)).to(device)
+    g = torch.Generator(device=device).manual_seed(seed)
+    e_per = ei.size(1) // n_graphs
+    nf = torch.randn(n_graphs * N_NODES, D // 2, device=device, generator=g)
+    ef = torch.randn(ei.size(1), D // 2, device=device, generator=g)
+    return make_batch_concatenated(nf, ei, ef, [N_NODES] * n_graphs, [e_per] * n_graphs)
+
+
+def make_layer(device):
+    from hot_amd.models.common import KernelFeatureMap
+    from hot_amd.models.sparse import KernelSelfAttn
+    torch.manual_seed(0)
+    fmap = KernelFeatureMap(DQK // HEADS, generalized_attention=True)
+    return KernelSelfAttn(2, 2, D, DV, DQK, HEADS, 'default', 0., 0., fmap).to(device)
+
+
+def cpu_baseline(n_graphs=192, threads=None):
+    """The oracle (CPU restatement of the reference algorithm, kind 'port') on the host cores, same layer and
+    graph family, bounded sample."""
+    from oracle import hot_oracle as O
+    threads = threads or min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(99)
+    g = torch.Generator().manual_seed(99)
+    nfs, eis, efs = [], [], []
+    for _ in range(n_graphs):
+        ei = torch.from_numpy(O.ba_edges(N_NODES, BA_M, rng))
+        nfs.append(torch.randn(N_NODES, D // 2, generator=g)); eis.append(ei)
+        efs.append(torch.randn(ei.size(1), D // 2, generator=g))
+    G = O.build_batch_from_lists(nfs, eis, efs)
+    layer = make_layer('cpu')
+    sd = {k: v.detach().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
+          for k, v in layer.state_dict().items()}
+    n_entries = sum(G.n_edges)
+    best = None
+    for it in range(3):
+        x = G.values.clone().requires_grad_(True)
+        t0 = time.perf_counter()
+        y = O.kernel_self_attn(G.like(x), sd, 2, 2, D, DV, DQK, HEADS, 'default', True)
+        y.values.sum().backward()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    return {'value': n_entries / best, 'unit': 'entries/s', 'cores': threads, 'kind': 'port',
+            'sample': f'{n_graphs} BA(64,5) graphs = {n_entries} entries, fwd+bwd of the same layer, best of 3, '
+                      f'oracle/hot_oracle.py on torch-CPU fp32'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--entries', type=float, default=10e6, help='entries per GPU')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-kernel', default='auto', help='C-ABI entry point timed live with HIP events')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    from hot_amd import _lib
+    from hot_amd.batch.sparse import batch_like
+
+    n_graphs = max(1, int(round(args.entries / ENTRIES_PER_GRAPH)))
+    G = make_inputs(n_graphs, device, seed=1234 + rank)
+    n_entries = sum(G.n_edges)
+    n_offdiag = n_entries - sum(G.n_nodes)
+    layer = make_layer(device)
+    params = [p for p in layer.parameters()]
+    x0 = G.values
+
+    def step():
+        x = x0.detach().requires_grad_(True)
+        out = layer(batch_like(G, x, skip_masking=True))
+        out.values.sum().backward()
+        if dist is not None:
+            flat = torch.cat([p.grad.reshape(-1) for p in params])
+            dist.all_reduce(flat)
+        for p in params:
+            p.grad = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    # which C-ABI entry point to time live: the one with the largest share in a one-step census
+    if args.profile_kernel == 'auto':
+        _lib.timing_begin(None)
+        step()
+        torch.cuda.synchronize()
+        census = _lib.timing_end()
+        prof_name = max(census, key=lambda k: census[k][0]) if census else None
+    else:
+        census, prof_name = {}, args.profile_kernel
+    fence()
+    _lib.timing_begin(prof_name)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    timed = _lib.timing_end()
+    if dist is not None:
+        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    total_entries = n_entries * world
+    value = total_entries * args.steps / elapsed
+
+    if rank == 0:
+        bpe = BYTES_PER_ENTRY + BYTES_PER_NODE * sum(G.n_nodes) / n_entries
+        layer_frac = bpe * (value / world) / HBM_PEAK
+        roof = None
+        if prof_name and prof_name in timed:
+            tot_ms, calls, alg_bytes = timed[prof_name]
+            ach = alg_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+            roof = {'bound': 'hbm', 'kernel': prof_name, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
+                    'frac': ach * 1e9 / HBM_PEAK, 'traffic': None, 'launches': calls,
+                    'avg_launch_ms': tot_ms / max(calls, 1),
+                    'note': 'achieved = algorithmic bytes (operands read once + results written once) of the '
+                            'dominant C-ABI kernel / its HIP-event time inside the timed region'}
+        line = {
+            'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': value, 'unit': 'entries/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'S1/C1: {n_graphs} BA(64,5) graphs per GPU = {n_entries} entries '
+                                   f'({n_offdiag} off-diagonal), KernelSelfAttn(2,2,32,32,32,4) generalized FAVOR+ '
+                                   f'(d=8,m=16), fwd + sum().backward()',
+                       'entries_per_gpu': n_entries, 'parallelism': f'graph-minibatch dp{world}'},
+            'layer_roofline': {'bytes_per_entry': bpe, 'frac_of_hbm_peak_per_gpu': layer_frac,
+                               'note': 'SURVEY 8d whole-layer figure: attention-core algorithmic bytes x entries/s '
+                                       '/ 8 TB/s, GEMM time included in the denominator'},
+            'roofline': roof,
+            'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
+        }
+        if args.no_cpu_baseline or world > 1:
+            line['cpu_baseline'] = None
+        else:
+            line['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -76,6 +76,50 @@ def check(rc, what):
         raise HotkError(f'{what} failed: {lib().hotk_strerror(rc).decode()} ({rc})')
 
 
+# ------------------------------------------------------------------------------------------------
+# optional live timing of C-ABI launches with HIP events on the launch stream (used by bench.py)
+# ------------------------------------------------------------------------------------------------
+_timing = None   # None = off; else {'only': name or None, 'events': [(name, start, end, alg_bytes)]}
+
+
+def timing_begin(only=None):
+    """Record a HIP event pair around every launch of `only` (or of every entry point when None)."""
+    global _timing
+    _timing = {'only': only, 'events': []}
+
+
+def timing_end():
+    """-> {entry point: (total ms, launches, algorithmic bytes)}; synchronises the device."""
+    global _timing
+    t, _timing = _timing, None
+    out = {}
+    if not t:
+        return out
+    torch.cuda.synchronize()
+    for name, e0, e1, nbytes in t['events']:
+        ms, calls, b = out.get(name, (0.0, 0, 0))
+        out[name] = (ms + e0.elapsed_time(e1), calls + 1, b + nbytes)
+    return out
+
+
+def call(name, alg_bytes, *args):
+    """Invoke one C-ABI entry point on the current torch stream and raise on a non-zero status.
+    alg_bytes: the bytes this launch has to move at minimum (operands once + results once)."""
+    fn = getattr(lib(), name)
+    t = _timing
+    if t is not None and (t['only'] is None or t['only'] == name):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args, stream_ptr())
+        e1.record()
+        t['events'].append((name, e0, e1, int(alg_bytes)))
+    else:
+        rc = fn(*args, stream_ptr())
+    if rc != 0:
+        raise HotkError(f'{name} failed: {lib().hotk_strerror(rc).decode()} ({rc})')
+
+
 def require_device(t: torch.Tensor, what='tensor'):
     if not t.is_cuda:
         raise HotkError(f'hot_amd kernels run on a HIP device only; {what} is on {t.device}. '

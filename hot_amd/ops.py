@@ -9,7 +9,7 @@ import torch
 from torch.autograd import Function
 
 from . import _lib
-from ._lib import lib, p, check, stream_ptr, rows2d, KEEP_DIAG, KEEP_OFFDIAG, KEEP_VALID, SEG_CHUNK
+from ._lib import lib, p, check, call, stream_ptr, rows2d, KEEP_DIAG, KEEP_OFFDIAG, KEEP_VALID, SEG_CHUNK
 
 
 # ------------------------------------------------------------------------------------------------
@@ -21,7 +21,7 @@ def gather_rows(src, idx, n_out, out=None, accumulate=False):
         out = torch.empty(n_out, C, dtype=src.dtype, device=src.device)
     o, ldo, no, Co = rows2d(out)
     assert o.data_ptr() == out.data_ptr() and no == n_out and Co == C
-    check(lib().hotk_gather_rows(p(s), ld, p(idx), p(o), ldo, n_out, C, int(accumulate), stream_ptr()), 'hotk_gather_rows')
+    call('hotk_gather_rows', 8 * n_out * C + 4 * n_out, p(s), ld, p(idx), p(o), ldo, n_out, C, int(accumulate))
     return out
 
 
@@ -29,7 +29,7 @@ def mask_rows(src, kind, keep, fill=0.0):
     s, ld, n, C = rows2d(src)
     assert kind.numel() == n, (kind.numel(), n)
     out = torch.empty(src.shape, dtype=src.dtype, device=src.device)
-    check(lib().hotk_mask_rows(p(s), ld, p(kind), keep, c_float(fill), p(out), C, n, C, stream_ptr()), 'hotk_mask_rows')
+    call('hotk_mask_rows', 8 * n * C + n, p(s), ld, p(kind), keep, c_float(fill), p(out), C, n, C)
     return out
 
 
@@ -39,8 +39,7 @@ def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID):
     n_seg = beg.numel()
     alloc = torch.zeros if maxlen > SEG_CHUNK else torch.empty
     out = alloc(n_seg, C, dtype=src.dtype, device=src.device)
-    check(lib().hotk_seg_sum_rows(p(s), ld, p(beg), p(end), p(perm), p(kind), keep, p(out), C, n_seg, C, maxlen,
-                                  stream_ptr()), 'hotk_seg_sum_rows')
+    call('hotk_seg_sum_rows', 4 * C * (n + n_seg), p(s), ld, p(beg), p(end), p(perm), p(kind), keep, p(out), C, n_seg, C, maxlen)
     return out
 
 
@@ -57,8 +56,8 @@ def seg_outer_sum(K, kidx, V, vidx, aug, seg, HH, m, c):
     n_seg = beg.numel()
     alloc = torch.zeros if maxlen > SEG_CHUNK else torch.empty
     KV = alloc(n_seg, HH * m, c + 1, dtype=K.dtype, device=K.device)
-    check(lib().hotk_seg_outer_sum(p(k), ldk, p(kidx), p(v), ldv, p(vidx), p(a), lda, p(beg), p(end), p(perm), p(KV),
-                                   n_seg, HH, m, c, maxlen, stream_ptr()), 'hotk_seg_outer_sum')
+    call('hotk_seg_outer_sum', 4 * (v.numel() // max(Cv, 1)) * (Ck + Cv) + 4 * KV.numel(), p(k), ldk, p(kidx), p(v), ldv, p(vidx), p(a), lda, p(beg), p(end), p(perm), p(KV),
+                                   n_seg, HH, m, c, maxlen)
     return KV
 
 
@@ -68,8 +67,8 @@ def row_contract(Q, qidx, KV, sidx, seg_div, kind, keep, n, HH, m, c, normalize,
     n_out = n if n_out is None else n_out
     alloc = torch.zeros if oidx is not None else torch.empty
     out = alloc(n_out, HH * c, dtype=Q.dtype, device=Q.device)
-    check(lib().hotk_row_contract(p(q), ldq, p(qidx), p(KV), p(sidx), seg_div, p(kind), keep, p(oidx), p(out), HH * c, n,
-                                  HH, m, c, int(normalize), stream_ptr()), 'hotk_row_contract')
+    call('hotk_row_contract', 4 * n * HH * (m + c) + 4 * KV.numel(), p(q), ldq, p(qidx), p(KV), p(sidx), seg_div, p(kind), keep, p(oidx), p(out), HH * c, n,
+                                  HH, m, c, int(normalize))
     return out
 
 
@@ -79,8 +78,8 @@ def apply_bwd_stats(Q, KV, sidx, seg_div, kind, keep, dO, n, HH, m, c):
     assert ng == n and Cg == HH * c
     X = torch.empty(n, HH * c, dtype=Q.dtype, device=Q.device)
     XA = torch.empty(n, HH, dtype=Q.dtype, device=Q.device)
-    check(lib().hotk_apply_bwd_stats(p(q), ldq, p(KV), p(sidx), seg_div, p(kind), keep, p(g), ldg, p(X), HH * c, p(XA), HH,
-                                     n, HH, m, c, stream_ptr()), 'hotk_apply_bwd_stats')
+    call('hotk_apply_bwd_stats', 4 * n * HH * (m + 2 * c + 1) + 4 * KV.numel(), p(q), ldq, p(KV), p(sidx), seg_div, p(kind), keep, p(g), ldg, p(X), HH * c, p(XA), HH,
+                                     n, HH, m, c)
     return X, XA
 
 
@@ -92,8 +91,8 @@ def row_expand(KV, sidx, seg_div, X, xidx, XA, kind, keep, n, HH, m, c):
     else:
         a, lda = None, 0
     out = torch.empty(n, HH * m, dtype=X.dtype, device=X.device)
-    check(lib().hotk_row_expand(p(KV), p(sidx), seg_div, p(x), ldx, p(xidx), p(a), lda, p(kind), keep, p(out), HH * m, n,
-                                HH, m, c, stream_ptr()), 'hotk_row_expand')
+    call('hotk_row_expand', 4 * n * HH * (m + c) + 4 * KV.numel(), p(KV), p(sidx), seg_div, p(x), ldx, p(xidx), p(a), lda, p(kind), keep, p(out), HH * m, n,
+                                HH, m, c)
     return out
 
 
@@ -174,11 +173,9 @@ class Phi(Function):
             need = c_size_t(0)
             check(lib().hotk_phi_stats_workspace_bytes(n, HH, m, byref(need)), 'hotk_phi_stats_workspace_bytes')
             ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
-            check(lib().hotk_phi_key_stats(p(xs), ld, p(proj), n, HH, d, m, p(gstat), p(ws), need.value, stream_ptr()),
-                  'hotk_phi_key_stats')
+            call('hotk_phi_key_stats', 4 * n * HH * d, p(xs), ld, p(proj), n, HH, d, m, p(gstat), p(ws), need.value)
         out = torch.empty(*x.shape[:-1], HH * m, dtype=x.dtype, device=x.device)
-        check(lib().hotk_phi_fwd(p(xs), ld, p(proj), p(kind), keep, p(out), HH * m, n, HH, d, m, mode, p(gstat),
-                                 stream_ptr()), 'hotk_phi_fwd')
+        call('hotk_phi_fwd', 4 * n * HH * (d + m), p(xs), ld, p(proj), p(kind), keep, p(out), HH * m, n, HH, d, m, mode, p(gstat))
         ctx.save_for_backward(xs, proj, kind, gstat)
         ctx.cfg = (ld, n, HH, d, m, mode, keep, x.shape)
         return out
@@ -194,11 +191,11 @@ class Phi(Function):
             need = c_size_t(0)
             check(lib().hotk_phi_stats_workspace_bytes(n, HH, m, byref(need)), 'hotk_phi_stats_workspace_bytes')
             ws = torch.empty(need.value, dtype=torch.uint8, device=g.device)
-            check(lib().hotk_phi_key_bwd_stats(p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, n, HH, d, m, p(gstat),
-                                               p(ws), need.value, stream_ptr()), 'hotk_phi_key_bwd_stats')
+            call('hotk_phi_key_bwd_stats', 4 * n * HH * (d + m), p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, n, HH, d, m, p(gstat),
+                                               p(ws), need.value)
         dx = torch.empty(xshape, dtype=g.dtype, device=g.device)
-        check(lib().hotk_phi_bwd(p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, p(dx), HH * d, n, HH, d, m, mode,
-                                 p(gstat), stream_ptr()), 'hotk_phi_bwd')
+        call('hotk_phi_bwd', 4 * n * HH * (2 * d + m), p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, p(dx), HH * d, n, HH, d, m, mode,
+                                 p(gstat))
         return dx, None, None, None, None, None
 
 
@@ -210,8 +207,8 @@ class Basis22Light(Function):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R
         out = torch.empty(*x.shape[:-1], 5 * D, dtype=x.dtype, device=x.device)
-        check(lib().hotk_basis22_light_fwd(p(xs), ld, p(plan.kind), p(plan.rown), p(plan.coln), p(plan.tpos),
-                                           p(plan.diag_pos), p(out), 5 * D, n, D, stream_ptr()), 'hotk_basis22_light_fwd')
+        call('hotk_basis22_light_fwd', 24 * n * D, p(xs), ld, p(plan.kind), p(plan.rown), p(plan.coln), p(plan.tpos),
+                                           p(plan.diag_pos), p(out), 5 * D, n, D)
         ctx.plan = plan
         ctx.xshape = x.shape
         return out
@@ -222,9 +219,8 @@ class Basis22Light(Function):
         gs, ldg, n, C5 = rows2d(g)
         D = C5 // 5
         dx = torch.empty(ctx.xshape, dtype=g.dtype, device=g.device)
-        check(lib().hotk_basis22_light_bwd(p(gs), ldg, p(plan.kind), p(plan.rown), p(plan.tpos), p(plan.row_ptr),
-                                           p(plan.row_perm), p(plan.col_ptr), p(plan.col_perm), p(dx), D, n, D,
-                                           stream_ptr()), 'hotk_basis22_light_bwd')
+        call('hotk_basis22_light_bwd', 24 * n * D, p(gs), ldg, p(plan.kind), p(plan.rown), p(plan.tpos), p(plan.row_ptr),
+                                           p(plan.row_perm), p(plan.col_ptr), p(plan.col_perm), p(dx), D, n, D)
         return dx, None
 
 
@@ -236,7 +232,7 @@ class BiasMask(Function):
     def forward(ctx, y, kind, b_off, b_diag):
         ys, ld, n, C = rows2d(y)
         assert ys.data_ptr() == y.data_ptr(), 'BiasMask expects a row-contiguous tensor'
-        check(lib().hotk_bias_mask_rows(p(ys), ld, p(kind), p(b_off), p(b_diag), n, C, stream_ptr()), 'hotk_bias_mask_rows')
+        call('hotk_bias_mask_rows', 8 * n * C, p(ys), ld, p(kind), p(b_off), p(b_diag), n, C)
         ctx.mark_dirty(y)
         ctx.save_for_backward(kind)
         ctx.has = (b_off is not None, b_diag is not None)
@@ -249,8 +245,7 @@ class BiasMask(Function):
         db_off = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[0] else None
         db_diag = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[1] else None
         if db_off is not None or db_diag is not None:
-            check(lib().hotk_bias_grad_rows(p(gs), ld, p(kind), p(db_off), p(db_diag), n, C, stream_ptr()),
-                  'hotk_bias_grad_rows')
+            call('hotk_bias_grad_rows', 4 * n * C, p(gs), ld, p(kind), p(db_off), p(db_diag), n, C)
         return mask_rows(g, kind, KEEP_VALID, 0.0), None, db_off, db_diag
 
 
