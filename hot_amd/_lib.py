@@ -42,6 +42,26 @@ _SIGNATURES = {
     'hotk_apply_bwd_stats': [_P, _L, _P, _P, _L, _P, _U, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
     'hotk_row_expand': [_P, _P, _L, _P, _L, _P, _P, _L, _P, _U, _P, _L, _L, _I, _I, _I, _P],
 }
+
+
+class Attn22Args(ctypes.Structure):
+    """mirror of struct hotk_attn22_args (include/hotk.h)"""
+    _fields_ = ([(n, _L) for n in ('B', 'Emax', 'Nmax', 'R', 'Nn', 'D')] +
+                [(n, ctypes.c_int32) for n in ('H', 'm', 'd_head', 'c')] +
+                [(n, _P) for n in ('kind', 'nkind', 'rown', 'coln', 'tpos', 'diag_pos', 'col_ptr', 'col_perm',
+                                   'row_ptr', 'row_perm', 'n_entries', 'n_nodes')] +
+                [('h1', _P), ('ld_h1', _L), ('h2', _P), ('ld_h2', _L), ('v', _P), ('ld_v', _L), ('proj', _P),
+                 ('att', _P), ('ld_att', _L), ('kvg', _P),
+                 ('datt', _P), ('ld_datt', _L), ('dout', _P), ('ld_dout', _L),
+                 ('dh1', _P), ('ld_dh1', _L), ('dh2', _P), ('ld_dh2', _L), ('dv', _P), ('ld_dv', _L),
+                 ('ck', _P), ('dkvg', _P)])
+
+
+_SIGNATURES.update({
+    'hotk_attn22_workspace_bytes': [_L, _L, ctypes.POINTER(_S)],
+    'hotk_attn22_forward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
+    'hotk_attn22_backward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
+})
 EXPORTS = sorted(list(_SIGNATURES) + ['hotk_strerror', 'hotk_version'])
 
 _lib = None

@@ -1,0 +1,782 @@
+// Fused attention core of the 2->2 sparse kernel-attention layer for the headline shape
+// (4 heads x 16 random features = one 64-lane wavefront per slot; head width 8, value width 8,
+// generalized / ReLU FAVOR+ map).  Reference: models/sparse/kernelattn.py:119-159 calling
+// models/sparse/kernelattncoef.py:74-234 ten times; here the ten terms are produced by
+//
+//   graph sums   : one wave per row chunk keeps the four per-graph  sum phi(K) (x) [V|1]  in registers
+//   node segments: one wave per node j keeps the six per-node       sum_i phi(K_i) (x) [V_ij|1]  (36+18 floats
+//                  per lane) in registers while it walks column segment j, and immediately applies them to the
+//                  node's own query, to the entries of column j and to the entries of row j.  No key-value
+//                  tensor, no phi(Q)/phi(K) tensor and no transposed value copy ever reaches HBM.
+//
+// Lane l = (head h = l>>4, feature mm = l&15).  A lane computes phi for its (h,mm) from the raw 8-wide head
+// slice (wave-broadcast 16-B loads), products with the 8-wide value / gradient slice of head h, and the
+// 16-lane sums with xor-shuffles that stay inside the head (shuffle-transpose reduction: 8 results in 8 steps).
+#include "common.h"
+
+namespace {
+
+constexpr int NH = 4, NM = 16, DH = 8, NC = 8;  // heads, features, head width, value width per head
+constexpr int SLOT = 32;                        // floats per dim_qk / dim_v slot (NH*DH == NH*NC == 32)
+constexpr float PHI_EPS = 1e-3f;
+
+using A = hotk_attn22_args;
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+struct Lane {
+  int lane, h, mm;
+  float ps[DH];  // P[mm][:] * d^-1/4
+};
+
+__device__ __forceinline__ Lane make_lane(const float* __restrict__ proj) {
+  Lane L;
+  L.lane = threadIdx.x & 63;
+  L.h = L.lane >> 4;
+  L.mm = L.lane & 15;
+  const float scale = 0.59460355750136051f;  // 8^-1/4
+#pragma unroll
+  for (int j = 0; j < DH; ++j) L.ps[j] = proj[L.mm * DH + j] * scale;
+  return L;
+}
+
+// pre-activation of feature (h,mm) for the raw 32-wide slot at x
+__device__ __forceinline__ float pre_of(const Lane& L, const float* __restrict__ x) {
+  float4 a = ld4(x + L.h * DH), b = ld4(x + L.h * DH + 4);
+  float s = a.x * L.ps[0];
+  s = fmaf(a.y, L.ps[1], s); s = fmaf(a.z, L.ps[2], s); s = fmaf(a.w, L.ps[3], s);
+  s = fmaf(b.x, L.ps[4], s); s = fmaf(b.y, L.ps[5], s); s = fmaf(b.z, L.ps[6], s); s = fmaf(b.w, L.ps[7], s);
+  return s;
+}
+__device__ __forceinline__ float phi_of(float pre) { return fmaxf(pre, 0.f) + PHI_EPS; }
+
+// load the 8-wide slice of head h of a 32-wide slot (zeros if p == nullptr)
+__device__ __forceinline__ void ld8(const Lane& L, const float* __restrict__ p, float (&o)[NC]) {
+  if (p) {
+    float4 a = ld4(p + L.h * NC), b = ld4(p + L.h * NC + 4);
+    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+  } else {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) o[c] = 0.f;
+  }
+}
+
+// sum over the 16 lanes of a head, result in every lane
+__device__ __forceinline__ float head_allsum(float v) {
+  v += __shfl_xor(v, 8, 64);
+  v += __shfl_xor(v, 4, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 1, 64);
+  return v;
+}
+
+// t[0..7] per lane -> sum over the head's 16 lanes of t[idx], idx = mm>>1, valid in every lane (pairs hold copies)
+__device__ __forceinline__ float head_sum8(const Lane& L, const float (&t)[8]) {
+  const bool b3 = L.mm & 8, b2 = L.mm & 4, b1 = L.mm & 2;
+  float w[4], u[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float give = b3 ? t[k] : t[k + 4];
+    float keep = b3 ? t[k + 4] : t[k];
+    w[k] = keep + __shfl_xor(give, 8, 64);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float give = b2 ? w[k] : w[k + 2];
+    float keep = b2 ? w[k + 2] : w[k];
+    u[k] = keep + __shfl_xor(give, 4, 64);
+  }
+  float give = b1 ? u[0] : u[1];
+  float keep = b1 ? u[1] : u[0];
+  float r = keep + __shfl_xor(give, 2, 64);
+  r += __shfl_xor(r, 1, 64);
+  return r;
+}
+
+// store the head_sum8 result: slot base p (32 floats), element h*8 + (mm>>1), one lane of each pair
+__device__ __forceinline__ void st_sum8(const Lane& L, float* __restrict__ p, float r) {
+  if ((L.mm & 1) == 0) p[L.h * 8 + (L.mm >> 1)] = r;
+}
+
+__device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
+  for (int i = L.lane; i < nslots * SLOT; i += 64) p[i] = 0.f;
+}
+
+// KV accumulate: kv[0..7] += phi * val, kv[8] += phi
+__device__ __forceinline__ void kv_acc(float (&kv)[NC + 1], float phi, const float (&val)[NC]) {
+#pragma unroll
+  for (int c = 0; c < NC; ++c) kv[c] = fmaf(phi, val[c], kv[c]);
+  kv[NC] += phi;
+}
+
+// O = phi(q).KV / guard(phi(q).ks) for one slot; writes 32 floats at out
+__device__ __forceinline__ void apply_fwd(const Lane& L, const float* __restrict__ q, const float (&kv)[NC + 1],
+                                          float* __restrict__ out) {
+  const float phi = phi_of(pre_of(L, q));
+  float t[8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) t[c] = phi * kv[c];
+  float den = head_allsum(phi * kv[NC]);
+  if (den == 0.f) den = 1e-5f;
+  float r = head_sum8(L, t);
+  st_sum8(L, out, r / den);
+}
+
+// backward of apply_fwd: writes d(raw q) (32 floats at dq) and accumulates dkv
+__device__ __forceinline__ void apply_bwd(const Lane& L, const float* __restrict__ q, const float (&kv)[NC + 1],
+                                          const float* __restrict__ dO, float* __restrict__ dq,
+                                          float (&dkv)[NC + 1]) {
+  const float pre = pre_of(L, q);
+  const float phi = phi_of(pre);
+  float g[NC];
+  ld8(L, dO, g);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s = fmaf(kv[c], g[c], s);
+  float den = head_allsum(phi * kv[NC]);
+  const float dot = head_allsum(phi * s);
+  const bool guarded = (den == 0.f);
+  if (guarded) den = 1e-5f;
+  const float inv = 1.f / den;
+  const float dden = guarded ? 0.f : -dot * inv * inv;
+  const float dphi = fmaf(kv[NC], dden, s * inv);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) dkv[c] = fmaf(phi, g[c] * inv, dkv[c]);
+  dkv[NC] = fmaf(phi, dden, dkv[NC]);
+  const float dpre = pre > 0.f ? dphi : 0.f;
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
+  st_sum8(L, dq, head_sum8(L, t));
+}
+
+// backward of one KV accumulation term: dV (32 floats at dv, may be null) and d(raw key) (32 floats at dk)
+__device__ __forceinline__ void kv_bwd(const Lane& L, const float* __restrict__ k, const float* __restrict__ val_p,
+                                       const float (&dkv)[NC + 1], float* __restrict__ dv, float* __restrict__ dk) {
+  const float pre = pre_of(L, k);
+  const float phi = phi_of(pre);
+  float val[NC];
+  ld8(L, val_p, val);
+  float t[8];
+  float dphi = dkv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    t[c] = phi * dkv[c];
+    dphi = fmaf(dkv[c], val[c], dphi);
+  }
+  float r = head_sum8(L, t);
+  if (dv) st_sum8(L, dv, r);
+  const float dpre = pre > 0.f ? dphi : 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
+  st_sum8(L, dk, head_sum8(L, t));
+}
+
+// ---- register-slice forms: the 8-wide head slices come out of the wave's LDS staging row --------------------
+__device__ __forceinline__ float pre_x(const Lane& L, const float (&x)[DH]) {
+  float s = x[0] * L.ps[0];
+#pragma unroll
+  for (int j = 1; j < DH; ++j) s = fmaf(x[j], L.ps[j], s);
+  return s;
+}
+
+__device__ __forceinline__ void slice8(const Lane& L, const float* lds_slot, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(lds_slot + L.h * 8);
+  const float4 b = *reinterpret_cast<const float4*>(lds_slot + L.h * 8 + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+
+template <int NR>
+__device__ __forceinline__ void stage_put(const Lane& L, float* stage, const float (&r)[NR]) {
+  // The staging row is private to the wave and the LDS executes one wave's instructions in order, so only the
+  // COMPILER has to be kept from moving the cross-lane reads over the writes: wavefront-scope fences.
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int t = 0; t < NR; ++t) stage[t * 64 + L.lane] = r[t];
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ void apply_fwd_x(const Lane& L, const float (&q)[DH], const float (&kv)[NC + 1],
+                                            float* __restrict__ out) {
+  const float phi = phi_of(pre_x(L, q));
+  float t[8];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) t[c] = phi * kv[c];
+  float den = head_allsum(phi * kv[NC]);
+  if (den == 0.f) den = 1e-5f;
+  st_sum8(L, out, head_sum8(L, t) / den);
+}
+
+__device__ __forceinline__ void apply_bwd_x(const Lane& L, const float (&q)[DH], const float (&kv)[NC + 1],
+                                            const float (&g)[NC], float* __restrict__ dq, float (&dkv)[NC + 1]) {
+  const float pre = pre_x(L, q);
+  const float phi = phi_of(pre);
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) s = fmaf(kv[c], g[c], s);
+  float den = head_allsum(phi * kv[NC]);
+  const float dot = head_allsum(phi * s);
+  const bool guarded = (den == 0.f);
+  if (guarded) den = 1e-5f;
+  const float inv = 1.f / den;
+  const float dden = guarded ? 0.f : -dot * inv * inv;
+  const float dphi = fmaf(kv[NC], dden, s * inv);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) dkv[c] = fmaf(phi, g[c] * inv, dkv[c]);
+  dkv[NC] = fmaf(phi, dden, dkv[NC]);
+  const float dpre = pre > 0.f ? dphi : 0.f;
+  float t[8];
+#pragma unroll
+  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
+  st_sum8(L, dq, head_sum8(L, t));
+}
+
+__device__ __forceinline__ void kv_bwd_x(const Lane& L, const float (&k)[DH], const float (&val)[NC],
+                                         const float (&dkv)[NC + 1], float* __restrict__ dv, float* __restrict__ dk) {
+  const float pre = pre_x(L, k);
+  const float phi = phi_of(pre);
+  float t[8];
+  float dphi = dkv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    t[c] = phi * dkv[c];
+    dphi = fmaf(dkv[c], val[c], dphi);
+  }
+  const float r = head_sum8(L, t);
+  if (dv) st_sum8(L, dv, r);
+  const float dpre = pre > 0.f ? dphi : 0.f;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
+  st_sum8(L, dk, head_sum8(L, t));
+}
+
+// Software pipeline over `cnt` items: the NR coalesced row loads of item k+1 are in flight while item k is
+// consumed (two named register sets, so every access is statically indexed).
+template <int NR, class LoadF, class UseF>
+__device__ __forceinline__ void pipeline2(int cnt, LoadF load, UseF use) {
+  if (cnt <= 0) return;
+  float ra[NR], rb[NR];
+  load(0, ra);
+  for (int k = 0; k < cnt; k += 2) {
+    const bool hb = k + 1 < cnt;
+    if (hb) load(k + 1, rb);
+    use(k, ra);
+    if (hb) {
+      if (k + 2 < cnt) load(k + 2, ra);
+      use(k + 1, rb);
+    }
+  }
+}
+
+__device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+
+// per-graph KV registers <-> memory, layout [B][4][9][64]
+__device__ __forceinline__ void kvg_load(const Lane& L, const float* __restrict__ base, float (&kv)[NC + 1]) {
+#pragma unroll
+  for (int c = 0; c <= NC; ++c) kv[c] = base[c * 64 + L.lane];
+}
+__device__ __forceinline__ void kvg_store(const Lane& L, float* __restrict__ base, const float (&kv)[NC + 1]) {
+#pragma unroll
+  for (int c = 0; c <= NC; ++c) base[c * 64 + L.lane] = kv[c];
+}
+template <int S>
+__device__ __forceinline__ void kv_zero(float (&kv)[S][NC + 1]) {
+#pragma unroll
+  for (int s = 0; s < S; ++s)
+#pragma unroll
+    for (int c = 0; c <= NC; ++c) kv[s][c] = 0.f;
+}
+
+// h1 slots: q1 = 0..3, k1 = 4..11;  h2 slots: q2 = 0..5, k2 = 6..7, skip path after slot 7
+// v slots 0..5 feed the node-segment terms, 6..9 the per-graph terms
+constexpr int K1 = 4, K2 = 6;
+constexpr int STAGE_FLOATS = 6 * 64;
+
+// ------------------------------------------------------------------------------------------------
+// per-graph sums (forward): wave per (graph, row chunk); rows are consecutive, two coalesced loads per row
+//   diagonal row (node n):  keys k1 slots 6,7 = h1[n][10*32 .. 12*32),  values v slots 6, 8
+//   off-diagonal row     :  keys k2 slots 0,1 = h2[r][ 6*32 ..  8*32),  values v slots 7, 9
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void chunk_rows(const A& a, int64_t w, int cpg, int rows_per_chunk, int64_t* b, int64_t* r0,
+                                           int64_t* r1) {
+  *b = w / cpg;
+  const int64_t k = w - *b * cpg;
+  *r0 = *b * a.Emax + k * rows_per_chunk;
+  int64_t e = *r0 + rows_per_chunk;
+  const int64_t rend = *b * a.Emax + a.n_entries[*b];
+  *r1 = e < rend ? e : rend;
+}
+
+__global__ __launch_bounds__(256) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+  const Lane L = make_lane(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
+  const int64_t nwork = a.B * cpg;
+  const bool lo = L.lane < 32;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+    int64_t b, r0, r1;
+    chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
+    const int64_t nodes_end = b * a.Emax + a.n_nodes[b];   // rows below are the diagonal (layout invariant)
+    float kv[4][NC + 1];
+    kv_zero<4>(kv);
+    auto load = [&](int k, float (&r)[2]) {
+      const int64_t row = r0 + k;
+      const float* vr = a.v + row * a.ld_v;
+      if (row < nodes_end) {
+        const int64_t n = b * a.Nmax + (row - b * a.Emax);
+        r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
+        r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];          // slot 6 | slot 8
+      } else {
+        r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+        r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];          // slot 7 | slot 9
+      }
+    };
+    auto use = [&](int k, const float (&r)[2]) {
+      const bool diag = (r0 + k) < nodes_end;
+      stage_put<2>(L, stage, r);
+      float x[8], val[8];
+      slice8(L, stage, x); slice8(L, stage + 64, val);
+      const float p0 = phi_of(pre_x(L, x));
+      if (diag) kv_acc(kv[0], p0, val); else kv_acc(kv[1], p0, val);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+      const float p1 = phi_of(pre_x(L, x));
+      if (diag) kv_acc(kv[2], p1, val); else kv_acc(kv[3], p1, val);
+    };
+    pipeline2<2>((int)(r1 - r0), load, use);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kvg_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, kv[s]);
+  }
+}
+
+// out[b][x] = sum_k part[b*cpg + k][x], x over 4*9*64 floats
+__global__ void k_graph_reduce(const float* __restrict__ part, float* __restrict__ out, int64_t B, int cpg) {
+  const int64_t X = 4 * (NC + 1) * 64, total = B * X;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t b = t / X, x = t - b * X;
+    float s = 0.f;
+    for (int k = 0; k < cpg; ++k) s += part[((int64_t)b * cpg + k) * X + x];
+    out[t] = s;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node segments: wave per node.  Segment entries are fetched 64 at a time (entry id, row node, transposed
+// position, kind: one lane each), then walked with uniform readlane indices and the 2-deep row pipeline.
+// ------------------------------------------------------------------------------------------------
+struct SegBlock {
+  int32_t e, i, te, kd;
+};
+
+__device__ __forceinline__ SegBlock seg_block(const Lane& L, const A& a, const int32_t* __restrict__ perm, int32_t base,
+                                              int cnt, bool want_keys) {
+  SegBlock s{0, 0, -1, 0};
+  if (L.lane < cnt) {
+    s.e = perm[base + L.lane];
+    s.kd = a.kind[s.e];
+    if (want_keys) {
+      s.i = a.rown[s.e];
+      s.te = a.tpos[s.e];
+    }
+  }
+  return s;
+}
+
+// six coalesced loads for one column-segment entry e = (i, j): key slots 0..5 of node i, value slots
+// {0 | 1t}, {2 | 3t}, {4t | 5} with the transposed slots (t) read from row te (zeros when absent)
+__device__ __forceinline__ void load_kv_rows(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[6]) {
+  const float* kp = a.h1 + (int64_t)i * a.ld_h1 + K1 * SLOT;
+  r[0] = kp[L.lane];
+  r[1] = kp[64 + L.lane];
+  r[2] = kp[128 + L.lane];
+  const bool lo = L.lane < 32;
+  const int32_t ra = lo ? e : te, rb = lo ? te : e;
+  const float* va = a.v + (int64_t)(ra < 0 ? 0 : ra) * a.ld_v;
+  const float* vb = a.v + (int64_t)(rb < 0 ? 0 : rb) * a.ld_v;
+  const float x3 = va[L.lane], x4 = va[64 + L.lane], x5 = vb[128 + L.lane];
+  r[3] = ra < 0 ? 0.f : x3;
+  r[4] = ra < 0 ? 0.f : x4;
+  r[5] = rb < 0 ? 0.f : x5;
+}
+
+template <class F>
+__device__ __forceinline__ void for_col_entries_kv(const Lane& L, const A& a, float* stage, int32_t n,
+                                                   F per_entry) {
+  const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
+  for (int32_t base = c0; base < c1; base += 64) {
+    const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+    const SegBlock sb = seg_block(L, a, a.col_perm, base, cnt, true);
+    auto load = [&](int k, float (&r)[6]) { load_kv_rows(L, a, rl(sb.e, k), rl(sb.i, k), rl(sb.te, k), r); };
+    auto use = [&](int k, const float (&r)[6]) {
+      stage_put<6>(L, stage, r);
+      per_entry(rl(sb.e, k), rl(sb.te, k));
+    };
+    pipeline2<6>(cnt, load, use);
+  }
+}
+
+__device__ __forceinline__ void colseg_accumulate(const Lane& L, const A& a, float* stage, int32_t n,
+                                                  float (&kv)[6][NC + 1]) {
+  kv_zero<6>(kv);
+  for_col_entries_kv(L, a, stage, n, [&](int32_t, int32_t) {
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+      float x[8], val[8];
+      slice8(L, stage + s * SLOT, x);
+      slice8(L, stage + 192 + s * SLOT, val);
+      kv_acc(kv[s], phi_of(pre_x(L, x)), val);
+    }
+  });
+}
+
+__global__ __launch_bounds__(256) void k_colseg_fwd(A a) {
+  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+  const Lane L = make_lane(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
+  const bool lo = L.lane < 32;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * 4) {
+    if (!a.nkind[n]) continue;
+    float kv[6][NC + 1];
+    colseg_accumulate(L, a, stage, (int32_t)n, kv);
+    const int64_t b = n / a.Nmax;
+    const float* kvg = a.kvg + b * 4 * (NC + 1) * 64;
+    float g0[NC + 1], g1[NC + 1];
+    // node queries: terms 1, 2 (column sums) and 7, 8 (graph sums) go to the node's diagonal row
+    {
+      const float* q = a.h1 + n * a.ld_h1;
+      float* o = a.att + (int64_t)a.diag_pos[n] * a.ld_att;
+      float r[2] = {q[L.lane], q[64 + L.lane]};
+      kvg_load(L, kvg + 0 * (NC + 1) * 64, g0);
+      kvg_load(L, kvg + 1 * (NC + 1) * 64, g1);
+      stage_put<2>(L, stage, r);
+      float x[8];
+      slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[0], o + 0 * SLOT);
+      slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[1], o + 1 * SLOT);
+      slice8(L, stage + 2 * SLOT, x); apply_fwd_x(L, x, g0, o + 6 * SLOT);
+      slice8(L, stage + 3 * SLOT, x); apply_fwd_x(L, x, g1, o + 7 * SLOT);
+      zero_slots(L, o + 2 * SLOT, 4);
+      zero_slots(L, o + 8 * SLOT, 2);
+    }
+    kvg_load(L, kvg + 2 * (NC + 1) * 64, g0);
+    kvg_load(L, kvg + 3 * (NC + 1) * 64, g1);
+    // entries of column n: terms 3, 5 (this node's sums) and 9, 10 (graph sums)
+    {
+      const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
+      for (int32_t base = c0; base < c1; base += 64) {
+        const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+        const SegBlock sb = seg_block(L, a, a.col_perm, base, cnt, false);
+        auto load = [&](int k, float (&r)[2]) {
+          const float* q = a.h2 + (int64_t)rl(sb.e, k) * a.ld_h2;
+          r[0] = q[L.lane];               // query slots 0, 1
+          r[1] = q[4 * SLOT + L.lane];    // query slots 4, 5
+        };
+        auto use = [&](int k, const float (&r)[2]) {
+          if (rl(sb.kd, k) != 2) return;
+          float* o = a.att + (int64_t)rl(sb.e, k) * a.ld_att;
+          stage_put<2>(L, stage, r);
+          float x[8];
+          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[2], o + 2 * SLOT);
+          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[3], o + 4 * SLOT);
+          slice8(L, stage + 2 * SLOT, x); apply_fwd_x(L, x, g0, o + 8 * SLOT);
+          slice8(L, stage + 3 * SLOT, x); apply_fwd_x(L, x, g1, o + 9 * SLOT);
+          o[L.lane] = 0.f;                 // terms 1, 2 live on the diagonal only
+          o[6 * SLOT + L.lane] = 0.f;      // terms 7, 8 too
+        };
+        pipeline2<2>(cnt, load, use);
+      }
+    }
+    // entries of row n: terms 4, 6 read the sums of their ROW node
+    {
+      const int32_t c0 = a.row_ptr[n], c1 = a.row_ptr[n + 1];
+      for (int32_t base = c0; base < c1; base += 64) {
+        const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+        const SegBlock sb = seg_block(L, a, a.row_perm, base, cnt, false);
+        auto load = [&](int k, float (&r)[1]) { r[0] = a.h2[(int64_t)rl(sb.e, k) * a.ld_h2 + 2 * SLOT + L.lane]; };
+        auto use = [&](int k, const float (&r)[1]) {
+          if (rl(sb.kd, k) != 2) return;
+          float* o = a.att + (int64_t)rl(sb.e, k) * a.ld_att;
+          stage_put<1>(L, stage, r);
+          float x[8];
+          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[4], o + 3 * SLOT);
+          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[5], o + 5 * SLOT);
+        };
+        pipeline2<1>(cnt, load, use);
+      }
+    }
+    (void)lo;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-graph terms (backward): (1) query side + dKVg partials, (2) key/value side
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+  const Lane L = make_lane(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
+  const int64_t nwork = a.B * cpg;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+    int64_t b, r0, r1;
+    chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
+    const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
+    float kv[4][NC + 1], dkv[4][NC + 1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kvg_load(L, a.kvg + ((int64_t)b * 4 + s) * (NC + 1) * 64, kv[s]);
+    kv_zero<4>(dkv);
+    auto load = [&](int k, float (&r)[2]) {
+      const int64_t row = r0 + k;
+      const float* g = a.datt + row * a.ld_datt;
+      if (row < nodes_end) {
+        const int64_t n = b * a.Nmax + (row - b * a.Emax);
+        r[0] = a.h1[n * a.ld_h1 + 2 * SLOT + L.lane];     // node query slots 2, 3
+        r[1] = g[6 * SLOT + L.lane];                       // d term 7, 8
+      } else {
+        r[0] = a.h2[row * a.ld_h2 + 4 * SLOT + L.lane];   // entry query slots 4, 5
+        r[1] = g[8 * SLOT + L.lane];                       // d term 9, 10
+      }
+    };
+    auto use = [&](int k, const float (&r)[2]) {
+      const int64_t row = r0 + k;
+      const bool diag = row < nodes_end;
+      stage_put<2>(L, stage, r);
+      float x[8], g[8];
+      float* dq = diag ? a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 2 * SLOT
+                       : a.dh2 + row * a.ld_dh2 + 4 * SLOT;
+      slice8(L, stage, x); slice8(L, stage + 64, g);
+      if (diag) apply_bwd_x(L, x, kv[0], g, dq, dkv[0]); else apply_bwd_x(L, x, kv[2], g, dq, dkv[2]);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, g);
+      if (diag) apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]); else apply_bwd_x(L, x, kv[3], g, dq + SLOT, dkv[3]);
+    };
+    pipeline2<2>((int)(r1 - r0), load, use);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kvg_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, dkv[s]);
+  }
+}
+
+// wave per chunk of 16 consecutive rows of one graph
+constexpr int GB_ROWS = 16;
+__global__ __launch_bounds__(256) void k_graphsum_bwd(A a) {
+  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+  const Lane L = make_lane(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
+  const bool lo = L.lane < 32;
+  const int64_t cpg = (a.Emax + GB_ROWS - 1) / GB_ROWS;
+  const int64_t nwork = a.B * cpg;
+  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+    int64_t b, r0, r1;
+    chunk_rows(a, w, (int)cpg, GB_ROWS, &b, &r0, &r1);
+    if (r1 <= r0) continue;
+    const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
+    const float* dkvg = a.dkvg + b * 4 * (NC + 1) * 64;
+    float d[4][NC + 1];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kvg_load(L, dkvg + s * (NC + 1) * 64, d[s]);
+    auto load = [&](int k, float (&r)[3]) {
+      const int64_t row = r0 + k;
+      const float* vr = a.v + row * a.ld_v;
+      if (row < nodes_end) {
+        const int64_t n = b * a.Nmax + (row - b * a.Emax);
+        r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
+        r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];
+      } else {
+        r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+        r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];
+      }
+      r[2] = (a.dout && L.lane < a.D) ? a.dout[row * a.ld_dout + L.lane] : 0.f;
+    };
+    auto use = [&](int k, const float (&r)[3]) {
+      const int64_t row = r0 + k;
+      const bool diag = row < nodes_end;
+      stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
+      float* dvr = a.dv + row * a.ld_dv;
+      float* dh2r = a.dh2 + row * a.ld_dh2;
+      float x[8], val[8];
+      if (diag) {
+        float* dkn = a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 10 * SLOT;
+        slice8(L, stage, x); slice8(L, stage + 64, val);
+        kv_bwd_x(L, x, val, d[0], dvr + 6 * SLOT, dkn);
+        slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+        kv_bwd_x(L, x, val, d[2], dvr + 8 * SLOT, dkn + SLOT);
+        if (lo) { dvr[7 * SLOT + L.lane] = 0.f; dvr[9 * SLOT + L.lane] = 0.f; }
+        zero_slots(L, dh2r, 8);   // entry-level queries / keys are masked on the diagonal
+      } else {
+        slice8(L, stage, x); slice8(L, stage + 64, val);
+        kv_bwd_x(L, x, val, d[1], dvr + 7 * SLOT, dh2r + K2 * SLOT);
+        slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+        kv_bwd_x(L, x, val, d[3], dvr + 9 * SLOT, dh2r + (K2 + 1) * SLOT);
+        if (lo) { dvr[6 * SLOT + L.lane] = 0.f; dvr[8 * SLOT + L.lane] = 0.f; }
+      }
+      // skip path: d h2[:, 8 slots:] = d out (zero when the caller routes that gradient elsewhere)
+      if (L.lane < a.D) dh2r[8 * SLOT + L.lane] = r[2];
+      for (int i = 64 + L.lane; i < a.D; i += 64) dh2r[8 * SLOT + i] = a.dout ? a.dout[row * a.ld_dout + i] : 0.f;
+    };
+    pipeline2<3>((int)(r1 - r0), load, use);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// node segments (backward): wave per node
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_colseg_bwd(A a) {
+  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+  const Lane L = make_lane(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
+  const bool lo = L.lane < 32;
+  for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * 4) {
+    if (!a.nkind[n]) continue;
+    float kv[6][NC + 1], dkv[6][NC + 1];
+    colseg_accumulate(L, a, stage, (int32_t)n, kv);
+    kv_zero<6>(dkv);
+    {  // node queries (terms 1, 2)
+      const int64_t dr = a.diag_pos[n];
+      float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[dr * a.ld_datt + L.lane]};
+      float* dq = a.dh1 + n * a.ld_dh1;
+      stage_put<2>(L, stage, r);
+      float x[8], g[8];
+      slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
+      slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
+    }
+    {  // entries of column n (terms 3, 5)
+      const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
+      for (int32_t base = c0; base < c1; base += 64) {
+        const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+        const SegBlock sb = seg_block(L, a, a.col_perm, base, cnt, false);
+        auto load = [&](int k, float (&r)[2]) {
+          const int64_t e = rl(sb.e, k);
+          r[0] = a.h2[e * a.ld_h2 + L.lane];                                      // query slots 0, 1
+          r[1] = a.datt[e * a.ld_datt + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
+        };
+        auto use = [&](int k, const float (&r)[2]) {
+          if (rl(sb.kd, k) != 2) return;
+          float* dq = a.dh2 + (int64_t)rl(sb.e, k) * a.ld_dh2;
+          stage_put<2>(L, stage, r);
+          float x[8], g[8];
+          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[2], g, dq, dkv[2]);
+          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[3], g, dq + SLOT, dkv[3]);
+        };
+        pipeline2<2>(cnt, load, use);
+      }
+    }
+    {  // entries of row n (terms 4, 6)
+      const int32_t c0 = a.row_ptr[n], c1 = a.row_ptr[n + 1];
+      for (int32_t base = c0; base < c1; base += 64) {
+        const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+        const SegBlock sb = seg_block(L, a, a.row_perm, base, cnt, false);
+        auto load = [&](int k, float (&r)[2]) {
+          const int64_t e = rl(sb.e, k);
+          r[0] = a.h2[e * a.ld_h2 + 2 * SLOT + L.lane];                            // query slots 2, 3
+          r[1] = a.datt[e * a.ld_datt + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
+        };
+        auto use = [&](int k, const float (&r)[2]) {
+          if (rl(sb.kd, k) != 2) return;
+          float* dq = a.dh2 + (int64_t)rl(sb.e, k) * a.ld_dh2 + 2 * SLOT;
+          stage_put<2>(L, stage, r);
+          float x[8], g[8];
+          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[4], g, dq, dkv[4]);
+          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[5], g, dq + SLOT, dkv[5]);
+        };
+        pipeline2<2>(cnt, load, use);
+      }
+    }
+    // key / value side of the six column sums: dV to row e (slots 0,2,5) or its transposed row (slots 1,3,4),
+    // d(raw key) contributions to ck[e] (summed per row node afterwards)
+    for_col_entries_kv(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te) {
+      float* dve = a.dv + (int64_t)e * a.ld_dv;
+      float* dvt = te >= 0 ? a.dv + (int64_t)te * a.ld_dv : nullptr;
+      float* ck = a.ck + (int64_t)e * (6 * SLOT);
+#pragma unroll
+      for (int s = 0; s < 6; ++s) {
+        float x[8], val[8];
+        slice8(L, stage + s * SLOT, x);
+        slice8(L, stage + 192 + s * SLOT, val);
+        const bool tr = (s == 1 || s == 3 || s == 4);
+        float* dvp = tr ? (dvt ? dvt + s * SLOT : nullptr) : dve + s * SLOT;
+        kv_bwd_x(L, x, val, dkv[s], dvp, ck + s * SLOT);
+      }
+      if (te < 0) {  // no transposed partner writes these slots of row e
+        if (lo) dve[1 * SLOT + L.lane] = 0.f;
+        dve[3 * SLOT + L.lane] = 0.f;
+      }
+    });
+  }
+}
+
+int check_args(const A* a) {
+  if (!a) return HOTK_EINVAL;
+  if (a->H != NH || a->m != NM || a->d_head != DH || a->c != NC) return HOTK_EUNSUPPORTED;
+  if (a->B < 0 || a->Emax < 0 || a->Nmax < 0 || a->R != a->B * a->Emax || a->Nn != a->B * a->Nmax) return HOTK_EINVAL;
+  if (!a->h1 || !a->h2 || !a->v || !a->proj || !a->kind || !a->nkind || !a->rown || !a->coln || !a->tpos ||
+      !a->diag_pos || !a->col_ptr || !a->col_perm || !a->row_ptr || !a->row_perm || !a->n_entries || !a->n_nodes)
+    return HOTK_EINVAL;
+  if (a->ld_h1 < 12 * SLOT || a->ld_h2 < 8 * SLOT || a->ld_v < 10 * SLOT) return HOTK_EINVAL;
+  // 16-byte vector loads of 8-float head slices
+  if ((a->ld_h1 | a->ld_h2 | a->ld_v) & 3) return HOTK_EINVAL;
+  if (!hotk_aligned16(a->h1) || !hotk_aligned16(a->h2) || !hotk_aligned16(a->v)) return HOTK_EINVAL;
+  return HOTK_OK;
+}
+
+void chunking(const A* a, int* cpg, int* rows) {
+  int64_t c = (a->Emax + 255) / 256;
+  if (c > 1024) c = 1024;
+  if (c < 1) c = 1;
+  *cpg = (int)c;
+  *rows = (int)((a->Emax + c - 1) / c);
+}
+
+}  // namespace
+
+extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes) {
+  HOTK_CHECK_ARG(bytes && B >= 0 && Emax >= 0);
+  int64_t c = (Emax + 255) / 256;
+  if (c > 1024) c = 1024;
+  if (c < 1) c = 1;
+  *bytes = (size_t)B * c * 4 * (NC + 1) * 64 * sizeof(float);
+  return HOTK_OK;
+}
+
+extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(a->att && a->kvg && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
+  if (a->R == 0 || a->Nn == 0) return HOTK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int cpg, rows;
+  chunking(a, &cpg, &rows);
+  size_t need;
+  hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
+  if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
+  float* part = cpg > 1 ? (float*)workspace : a->kvg;
+  unsigned g1 = hotk_grid(a->B * cpg, 4, 256 * 16);
+  hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(256), 0, st, *a, part, cpg, rows);
+  if (cpg > 1)
+    hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->kvg,
+                       a->B, cpg);
+  hipLaunchKernelGGL(k_colseg_fwd, dim3(hotk_grid(a->Nn, 4, 256 * 32)), dim3(256), 0, st, *a);
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(a->kvg && a->datt && a->dh1 && a->dh2 && a->dv && a->ck && a->dkvg);
+  HOTK_CHECK_ARG(a->ld_datt >= 10 * SLOT && a->ld_dh1 >= 12 * SLOT && a->ld_dh2 >= 8 * SLOT + a->D && a->D >= 0 &&
+                 a->ld_dv >= 10 * SLOT);
+  HOTK_CHECK_ARG(((a->ld_datt | a->ld_dh1 | a->ld_dh2 | a->ld_dv) & 3) == 0 && hotk_aligned16(a->datt));
+  HOTK_CHECK_ARG(!a->dout || a->ld_dout >= a->D);
+  if (a->R == 0 || a->Nn == 0) return HOTK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int cpg, rows;
+  chunking(a, &cpg, &rows);
+  size_t need;
+  hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
+  if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
+  float* part = cpg > 1 ? (float*)workspace : a->dkvg;
+  hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid(a->B * cpg, 4, 256 * 16)), dim3(256), 0, st, *a, part, cpg, rows);
+  if (cpg > 1)
+    hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->dkvg,
+                       a->B, cpg);
+  hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->R, 4, 256 * 32)), dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(k_colseg_bwd, dim3(hotk_grid(a->Nn, 4, 256 * 32)), dim3(256), 0, st, *a);
+  return hotk_launch_status();
+}

@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from ...batch.sparse import Batch as B, batch_like, t, v2d, d, add_batch
 from ..common.mudrop import MuDropout
+from ... import ops
 from .linear import Linear
 from .kernelattncoef import KernelFeatureMapWrapper, KernelAttnCoef
 
@@ -51,6 +52,7 @@ class KernelSelfAttn(nn.Module):
         self.reset_vo_parameters()
         self.dropout = nn.Dropout(p=dropout, inplace=True)
         self.mu_dropout = MuDropout(p=drop_mu)
+        self.use_fused = True   # fused HIP attention core when the shape allows it (see _fused_ok)
 
     def reset_vo_parameters(self):
         nn.init.xavier_normal_(self.fc_v.weight)
@@ -104,10 +106,22 @@ class KernelSelfAttn(nn.Module):
             att.append(self.att_1_2(q_1[3], k_2, v[3]))            # graph -> set (global)
         return add_batch(non_att, self._project_out(q_1[0], att))
 
+    def _fused_ok(self):
+        """the fused attention core covers the headline shape: 4 heads x 16 features (one wavefront per slot),
+        head width 8, value width 8, ReLU features, no (mu-)dropout, every term present"""
+        fm = self.feature_map.feature_map
+        return (self.use_fused and not self.is_local and fm.generalized_attention and self.n_heads == 4
+                and self.dim_qk == 32 and self.dim_v == 32 and self.feat_dim == 16
+                and (self.dropout.p == 0. or not self.training) and (self.mu_dropout.p == 0. or not self.training))
+
     def _2_to_2(self, G: B):
-        dqk = self.dim_qk
         h_1 = self.fc_1(G)                      # [B, N, 12 dqk]: 4 query slots, 8 key slots
         h_2 = self.fc_2(G)                      # [B, |E|, 8 dqk + D]: 6 query slots, 2 key slots, skip path
+        if self._fused_ok():
+            v = self.fc_v(G.values)             # padding rows are ignored by the kernels: no masking pass
+            out = ops.AttnCore22.apply(h_1.values, h_2.values, v, self.feature_map.feature_map.projection_matrix,
+                                       self.fc_o.weight, self.fc_o.bias, G.plan)
+            return batch_like(G, out, skip_masking=True)
         non_att = batch_like(h_2, h_2.values[..., -self.dim_in:], skip_masking=True)
         q_1 = self._phi_slots(h_1, 0, 4, True)
         k_1 = self._phi_slots(h_1, 4, 12, False)

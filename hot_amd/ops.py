@@ -308,3 +308,103 @@ class KernelAttn(Function):
         else:
             dk = seg_sum_rows(dkc, plan.row_seg())
         return dq.view(q.shape), dk.view(k.shape), dv.view(v.shape), None, None, None, None, None, None
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+class AttnCore22(Function):
+    """out = skip + mask(fc_o(cat(att_1..att_10))) for KernelSelfAttn(2,2) at the fused shape, straight from the raw
+    projections h1 = fc_1(G), h2 = fc_2(G), v = fc_v(values): the feature maps, the six per-node and four per-graph
+    key-value sums, their application, the transposes and the diagonal scatters all happen inside
+    hotk_attn22_forward / _backward (models/sparse/kernelattn.py:119-159 and everything it calls in
+    kernelattncoef.py).  The two dense projections around it stay library GEMMs."""
+
+    @staticmethod
+    def _args(plan, h1, h2, v, proj, D):
+        a = _lib.Attn22Args()
+        a.B, a.Emax, a.Nmax, a.R, a.Nn, a.D = plan.B, plan.Emax, plan.Nmax, plan.R, plan.Nn, D
+        a.H, a.m, a.d_head, a.c = 4, 16, 8, 8
+        for n in ('kind', 'nkind', 'rown', 'coln', 'tpos', 'diag_pos', 'col_ptr', 'col_perm', 'row_ptr', 'row_perm'):
+            setattr(a, n, getattr(plan, n).data_ptr())
+        a.n_entries = plan.n_entries_dev.data_ptr()
+        a.n_nodes = plan.n_nodes_dev.data_ptr()
+        a.h1, a.ld_h1 = h1.data_ptr(), h1.size(-1)
+        a.h2, a.ld_h2 = h2.data_ptr(), h2.size(-1)
+        a.v, a.ld_v = v.data_ptr(), v.size(-1)
+        a.proj = proj.data_ptr()
+        return a
+
+    @staticmethod
+    def _workspace(plan, dev):
+        need = c_size_t(0)
+        check(lib().hotk_attn22_workspace_bytes(plan.B, plan.Emax, byref(need)), 'hotk_attn22_workspace_bytes')
+        return torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev), need.value
+
+    @staticmethod
+    def forward(ctx, h1, h2, v, proj, w_o, b_o, plan):
+        for t_ in (h1, h2, v):
+            _lib.require_device(t_)
+            assert t_.is_contiguous() and t_.dtype == torch.float32
+        D = h2.size(-1) - 256
+        assert h1.size(-1) == 384 and v.size(-1) == 320 and D >= 0 and w_o.shape == (D, 320)
+        dev = h2.device
+        proj = proj.contiguous().float()
+        padded = plan.Ev != plan.R
+        att = (torch.zeros if padded else torch.empty)(plan.R, 320, dtype=torch.float32, device=dev)
+        kvg = torch.empty(plan.B, 4, 9, 64, dtype=torch.float32, device=dev)
+        a = AttnCore22._args(plan, h1, h2, v, proj, D)
+        a.att, a.ld_att, a.kvg = att.data_ptr(), 320, kvg.data_ptr()
+        ws, nws = AttnCore22._workspace(plan, dev)
+        call('hotk_attn22_forward', 4 * plan.Ev * (8 * 32 + 10 * 32 + 10 * 32) + 4 * plan.Nn * 384,
+             byref(a), p(ws), nws)
+        y = torch.addmm(b_o, att, w_o.t())
+        y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
+        out = y.add_(h2.view(plan.R, -1)[:, 256:]).view(*h2.shape[:-1], D)
+        ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg)
+        ctx.plan = plan
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        h1, h2, v, proj, w_o, att, kvg = ctx.saved_tensors
+        plan = ctx.plan
+        dev = h2.device
+        D = w_o.size(0)
+        d_out = d_out.contiguous().view(plan.R, D)
+        dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0)
+        datt = dy @ w_o
+        dw_o = dy.t() @ att
+        db_o = dy.sum(0)
+        padded = plan.Ev != plan.R
+        # padding rows of dh1 / dh2 are never read (the BiasMask backward of fc_1 / fc_2 selects valid rows only);
+        # dv feeds a plain GEMM, so its padding rows must be exact zeros
+        dh1 = torch.empty(plan.Nn, 384, dtype=torch.float32, device=dev)
+        dh2 = torch.empty(plan.R, 256 + D, dtype=torch.float32, device=dev)
+        dv = (torch.zeros if padded else torch.empty)(plan.R, 320, dtype=torch.float32, device=dev)
+        ck = torch.empty(plan.R, 192, dtype=torch.float32, device=dev)
+        dkvg = torch.empty_like(kvg)
+        a = AttnCore22._args(plan, h1, h2, v, proj, D)
+        a.kvg = kvg.data_ptr()
+        a.datt, a.ld_datt = datt.data_ptr(), 320
+        a.dout, a.ld_dout = d_out.data_ptr(), D
+        a.dh1, a.ld_dh1 = dh1.data_ptr(), 384
+        a.dh2, a.ld_dh2 = dh2.data_ptr(), 256 + D
+        a.dv, a.ld_dv = dv.data_ptr(), 320
+        a.ck, a.dkvg = ck.data_ptr(), dkvg.data_ptr()
+        ws, nws = AttnCore22._workspace(plan, dev)
+        call('hotk_attn22_backward', 4 * plan.Ev * (8 * 32 * 2 + 10 * 32 * 3 + 6 * 32) + 4 * plan.Nn * 384 * 2,
+             byref(a), p(ws), nws)
+        # d(raw key slots 0..5 of node i) = sum over the entries of row i of their per-entry contributions
+        beg, end, perm, maxlen = plan.row_seg()
+        if maxlen > SEG_CHUNK:
+            dh1[:, 128:320].zero_()
+        call('hotk_seg_sum_rows', 4 * 192 * (plan.Ev + plan.Nn), p(ck), 192, p(beg), p(end), p(perm), p(None),
+             KEEP_VALID, c_void_p_of(dh1, 128), 384, plan.Nn, 192, maxlen)
+        return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None
+
+
+def c_void_p_of(t, col):
+    from ctypes import c_void_p
+    return c_void_p(t.data_ptr() + 4 * col)

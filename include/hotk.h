@@ -163,6 +163,44 @@ int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const
                     const int32_t* xidx, const float* XA, int64_t ld_xa, const uint8_t* kind, unsigned keep,
                     float* out, int64_t ld_out, int64_t n, int HH, int m, int c, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused attention core of KernelSelfAttn(2,2) (models/sparse/kernelattn.py:119-159): all ten kernel-attention
+ * terms from the raw projections, for the shape 4 heads x 16 features (one wavefront per slot), head width 8,
+ * value width 8, generalized (ReLU) feature map.  Other shapes: HOTK_EUNSUPPORTED (use the general kernels).
+ *   h1  [Nn, >=12*32]  fc_1 output: raw query slots 0..3, raw key slots 4..11 (node level)
+ *   h2  [R,  >= 8*32]  fc_2 output: raw query slots 0..5, raw key slots 6..7 (entry level), skip path after them
+ *   v   [R,  >=10*32]  fc_v output (padding rows are ignored, they need not be zero)
+ *   att [R,  >=10*32]  the ten attention terms in the reference's concatenation order; valid rows are fully
+ *                      written, padding rows are left untouched (caller zero-fills when the batch has padding)
+ *   kvg [B,4,9,64]     per-graph sums (saved for the backward pass)
+ * backward: datt [R,10*32] -> dh1 [Nn,12*32] (key slots 4..9 are NOT written here: they are the row-segment sum of
+ * ck [R,6*32], hotk_seg_sum_rows over the row CSR), dh2 [R, 8*32 (+D)] (skip-path columns = dout when given,
+ * zero otherwise), dv [R,10*32]; padding rows of dh1/dh2/dv are left untouched.  dkvg [B,4,9,64] scratch.
+ * workspace: hotk_attn22_workspace_bytes(B, Emax) (per-chunk partial graph sums).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct hotk_attn22_args {
+  int64_t B, Emax, Nmax, R, Nn, D;
+  int32_t H, m, d_head, c;
+  const uint8_t *kind, *nkind;
+  const int32_t *rown, *coln, *tpos, *diag_pos, *col_ptr, *col_perm, *row_ptr, *row_perm, *n_entries, *n_nodes;
+  const float* h1; int64_t ld_h1;
+  const float* h2; int64_t ld_h2;
+  const float* v; int64_t ld_v;
+  const float* proj;
+  float* att; int64_t ld_att;
+  float* kvg;
+  const float* datt; int64_t ld_datt;
+  const float* dout; int64_t ld_dout;
+  float* dh1; int64_t ld_dh1;
+  float* dh2; int64_t ld_dh2;
+  float* dv; int64_t ld_dv;
+  float* ck;
+  float* dkvg;
+} hotk_attn22_args;
+int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes);
+int hotk_attn22_forward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
+int hotk_attn22_backward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

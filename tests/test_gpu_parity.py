@@ -171,16 +171,22 @@ def test_kernel_self_attn_layer_vs_reference(name):
             tag = f'{g}{oi}{oo}d'
             fmap = KernelFeatureMap(dim_qk // H, generalized_attention=(g == 'g'))
             layer = _load_layer(ms.KernelSelfAttn(oi, oo, D, dim_v, dim_qk, H, 'default', 0., 0., fmap), z, tag)
-            x = G0.values.clone().requires_grad_(True)
-            G = bs.batch_like(G0, x, skip_masking=True)
-            if oi == 1:
-                G = bs.d(G)
-            y = layer(G)
-            assert rel_err(y.values.detach().cpu(), z[f'{tag}/y']) < TOL, tag
-            (y.values * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
-            assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
-            for k, p_ in layer.named_parameters():
-                assert rel_err(p_.grad.cpu(), z[f'{tag}/grad/{k}']) < 2 * TOL, (tag, k)
+            for fused in (True, False):      # fused attention core (when the shape allows) and the general kernels
+                layer.use_fused = fused
+                layer.zero_grad()
+                x = G0.values.clone().requires_grad_(True)
+                G = bs.batch_like(G0, x, skip_masking=True)
+                if oi == 1:
+                    G = bs.d(G)
+                y = layer(G)
+                e = rel_err(y.values.detach().cpu(), z[f'{tag}/y'])
+                assert e < TOL, (tag, fused, e)
+                (y.values * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
+                e = rel_err(x.grad.cpu(), z[f'{tag}/gx'])
+                assert e < 2 * TOL, (tag, fused, e)
+                for k, p_ in layer.named_parameters():
+                    e = rel_err(p_.grad.cpu(), z[f'{tag}/grad/{k}'])
+                    assert e < 2 * TOL, (tag, fused, k, e)
     fmap = KernelFeatureMap(dim_qk // H, generalized_attention=True)
     enc = _load_layer(EncLayer(2, 2, D, dim_qk, dim_v, 2 * D, H, 'default', 'generalized_kernel', 0., 0., fmap), z, 'enc')
     x = G0.values.clone().requires_grad_(True)
@@ -203,8 +209,8 @@ def _ba_case(n_graphs, seed):
     return nfs, eis, efs, g
 
 
-@pytest.mark.parametrize('generalized', [False, True])
-def test_layer_vs_oracle_ba_graphs(generalized):
+@pytest.mark.parametrize('generalized,fused', [(False, False), (True, False), (True, True)])
+def test_layer_vs_oracle_ba_graphs(generalized, fused):
     """C1-shaped workload (BA(64,5) graphs, D = dqk = dv = 32, 4 heads) at a size the oracle runs in seconds.
 
     Softmax features are smooth: outputs and every gradient must agree to 1e-5 / 2e-5.
@@ -222,6 +228,7 @@ def test_layer_vs_oracle_ba_graphs(generalized):
     assert np.array_equal(G0.t_mask.cpu().numpy(), GO.t_mask.numpy())
     torch.manual_seed(0)
     layer = ms.KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8, generalized_attention=generalized)).to(DEV)
+    layer.use_fused = fused
     sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
           for k, v in layer.state_dict().items()}
     x = G0.values.clone().requires_grad_(True)
