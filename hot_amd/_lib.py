@@ -49,7 +49,7 @@ class Attn22Args(ctypes.Structure):
     _fields_ = ([(n, _L) for n in ('B', 'Emax', 'Nmax', 'R', 'Nn', 'D')] +
                 [(n, ctypes.c_int32) for n in ('H', 'm', 'd_head', 'c')] +
                 [(n, _P) for n in ('kind', 'nkind', 'rown', 'coln', 'tpos', 'diag_pos', 'col_ptr', 'col_perm',
-                                   'row_ptr', 'row_perm', 'n_entries', 'n_nodes')] +
+                                   'row_ptr', 'row_perm', 'n_entries', 'n_nodes', 'col_rec', 'row_rec')] +
                 [('h1', _P), ('ld_h1', _L), ('h2', _P), ('ld_h2', _L), ('v', _P), ('ld_v', _L), ('proj', _P),
                  ('att', _P), ('ld_att', _L), ('kvg', _P),
                  ('datt', _P), ('ld_datt', _L), ('dout', _P), ('ld_dout', _L),

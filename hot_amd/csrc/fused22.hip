@@ -61,41 +61,53 @@ __device__ __forceinline__ void ld8(const Lane& L, const float* __restrict__ p, 
   }
 }
 
+// ---- 16-lane (one DPP row = one head) reductions on the VALU: no LDS round trips ---------------------------
+// DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 // sum over the 16 lanes of a head, result in every lane
 __device__ __forceinline__ float head_allsum(float v) {
-  v += __shfl_xor(v, 8, 64);
-  v += __shfl_xor(v, 4, 64);
-  v += __shfl_xor(v, 2, 64);
-  v += __shfl_xor(v, 1, 64);
+  v += dpp<0xB1>(v);
+  v += dpp<0x4E>(v);
+  v += dpp<0x141>(v);
+  v += dpp<0x140>(v);
   return v;
 }
 
-// t[0..7] per lane -> sum over the head's 16 lanes of t[idx], idx = mm>>1, valid in every lane (pairs hold copies)
+// element index held by lane mm after head_sum8, and whether this lane is the one that stores it
+__device__ __forceinline__ int sum8_idx(int mm) { return 4 * (mm >> 3) + 2 * ((mm >> 2) & 1) + (mm & 1); }
+__device__ __forceinline__ bool sum8_owner(int mm) { return (mm & 2) == 0; }
+
+// t[0..7] per lane -> sum over the head's 16 lanes of t[sum8_idx(mm)] (shuffle-transpose reduction: each step
+// halves the number of live values while adding the mirrored partner's half)
 __device__ __forceinline__ float head_sum8(const Lane& L, const float (&t)[8]) {
-  const bool b3 = L.mm & 8, b2 = L.mm & 4, b1 = L.mm & 2;
+  const bool hi8 = L.mm & 8, hi4 = L.mm & 4, odd = L.mm & 1;
   float w[4], u[2];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    float give = b3 ? t[k] : t[k + 4];
-    float keep = b3 ? t[k + 4] : t[k];
-    w[k] = keep + __shfl_xor(give, 8, 64);
+    const float give = hi8 ? t[k] : t[k + 4];
+    const float keep = hi8 ? t[k + 4] : t[k];
+    w[k] = keep + dpp<0x140>(give);          // partner 15 - mm
   }
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
-    float give = b2 ? w[k] : w[k + 2];
-    float keep = b2 ? w[k + 2] : w[k];
-    u[k] = keep + __shfl_xor(give, 4, 64);
+    const float give = hi4 ? w[k] : w[k + 2];
+    const float keep = hi4 ? w[k + 2] : w[k];
+    u[k] = keep + dpp<0x141>(give);          // partner 7 - (mm & 7) within the half
   }
-  float give = b1 ? u[0] : u[1];
-  float keep = b1 ? u[1] : u[0];
-  float r = keep + __shfl_xor(give, 2, 64);
-  r += __shfl_xor(r, 1, 64);
+  const float give = odd ? u[0] : u[1];
+  const float keep = odd ? u[1] : u[0];
+  float r = keep + dpp<0xB1>(give);          // partner mm ^ 1
+  r += dpp<0x4E>(r);                         // partner mm ^ 2
   return r;
 }
 
-// store the head_sum8 result: slot base p (32 floats), element h*8 + (mm>>1), one lane of each pair
+// store the head_sum8 result: slot base p (32 floats), element h*8 + sum8_idx(mm)
 __device__ __forceinline__ void st_sum8(const Lane& L, float* __restrict__ p, float r) {
-  if ((L.mm & 1) == 0) p[L.h * 8 + (L.mm >> 1)] = r;
+  if (sum8_owner(L.mm)) p[L.h * 8 + sum8_idx(L.mm)] = r;
 }
 
 __device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
@@ -137,7 +149,7 @@ __device__ __forceinline__ void apply_bwd(const Lane& L, const float* __restrict
   const float dot = head_allsum(phi * s);
   const bool guarded = (den == 0.f);
   if (guarded) den = 1e-5f;
-  const float inv = 1.f / den;
+  const float inv = __builtin_amdgcn_rcpf(den);
   const float dden = guarded ? 0.f : -dot * inv * inv;
   const float dphi = fmaf(kv[NC], dden, s * inv);
 #pragma unroll
@@ -206,7 +218,7 @@ __device__ __forceinline__ void apply_fwd_x(const Lane& L, const float (&q)[DH],
   for (int c = 0; c < NC; ++c) t[c] = phi * kv[c];
   float den = head_allsum(phi * kv[NC]);
   if (den == 0.f) den = 1e-5f;
-  st_sum8(L, out, head_sum8(L, t) / den);
+  st_sum8(L, out, head_sum8(L, t) * __builtin_amdgcn_rcpf(den));
 }
 
 __device__ __forceinline__ void apply_bwd_x(const Lane& L, const float (&q)[DH], const float (&kv)[NC + 1],
@@ -220,7 +232,7 @@ __device__ __forceinline__ void apply_bwd_x(const Lane& L, const float (&q)[DH],
   const float dot = head_allsum(phi * s);
   const bool guarded = (den == 0.f);
   if (guarded) den = 1e-5f;
-  const float inv = 1.f / den;
+  const float inv = __builtin_amdgcn_rcpf(den);
   const float dden = guarded ? 0.f : -dot * inv * inv;
   const float dphi = fmaf(kv[NC], dden, s * inv);
 #pragma unroll
@@ -252,21 +264,26 @@ __device__ __forceinline__ void kv_bwd_x(const Lane& L, const float (&k)[DH], co
   st_sum8(L, dk, head_sum8(L, t));
 }
 
-// Software pipeline over `cnt` items: the NR coalesced row loads of item k+1 are in flight while item k is
-// consumed (two named register sets, so every access is statically indexed).
+// Software pipeline over `cnt` items, DEPTH 4: the NR coalesced row loads of items k+1..k+3 are in flight while
+// item k is consumed.  Four named register sets keep every access statically indexed; loads past the end are
+// clamped to the last item (a cache hit) so that the load stream is branch-free and the compiler can count it.
 template <int NR, class LoadF, class UseF>
-__device__ __forceinline__ void pipeline2(int cnt, LoadF load, UseF use) {
+__device__ __forceinline__ void pipeline4(int cnt, LoadF load, UseF use) {
   if (cnt <= 0) return;
-  float ra[NR], rb[NR];
-  load(0, ra);
-  for (int k = 0; k < cnt; k += 2) {
-    const bool hb = k + 1 < cnt;
-    if (hb) load(k + 1, rb);
-    use(k, ra);
-    if (hb) {
-      if (k + 2 < cnt) load(k + 2, ra);
-      use(k + 1, rb);
-    }
+  const int last = cnt - 1;
+  float r0[NR], r1[NR], r2[NR], r3[NR];
+  load(0, r0);
+  load(1 < last ? 1 : last, r1);
+  load(2 < last ? 2 : last, r2);
+  for (int k = 0; k < cnt; k += 4) {
+    load(k + 3 < last ? k + 3 : last, r3);
+    use(k, r0);
+    load(k + 4 < last ? k + 4 : last, r0);
+    if (k + 1 < cnt) use(k + 1, r1);
+    load(k + 5 < last ? k + 5 : last, r1);
+    if (k + 2 < cnt) use(k + 2, r2);
+    load(k + 6 < last ? k + 6 : last, r2);
+    if (k + 3 < cnt) use(k + 3, r3);
   }
 }
 
@@ -309,42 +326,48 @@ __device__ __forceinline__ void chunk_rows(const A& a, int64_t w, int cpg, int r
   *r1 = e < rend ? e : rend;
 }
 
+// rows [ra, rb) of graph b, all diagonal (DIAG) or all off-diagonal: two coalesced loads per row
+template <bool DIAG>
+__device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* stage, int64_t b, int64_t ra, int64_t rb,
+                                              float (&kv)[4][NC + 1]) {
+  const bool lo = L.lane < 32;
+  auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+    const int64_t row = ra + k;
+    const float* vr = a.v + row * a.ld_v;
+    if (DIAG) {
+      const int64_t n = b * a.Nmax + (row - b * a.Emax);
+      r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
+      r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];          // slot 6 | slot 8
+    } else {
+      r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+      r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];          // slot 7 | slot 9
+    }
+  };
+  auto use = [&](int, const float (&r)[2]) __attribute__((always_inline)) {
+    stage_put<2>(L, stage, r);
+    float x[8], val[8];
+    slice8(L, stage, x); slice8(L, stage + 64, val);
+    kv_acc(kv[DIAG ? 0 : 1], phi_of(pre_x(L, x)), val);
+    slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+    kv_acc(kv[DIAG ? 2 : 3], phi_of(pre_x(L, x)), val);
+  };
+  pipeline4<2>((int)(rb - ra), load, use);
+}
+
 __global__ __launch_bounds__(256) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
   __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  const bool lo = L.lane < 32;
   for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];   // rows below are the diagonal (layout invariant)
+    const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
     float kv[4][NC + 1];
     kv_zero<4>(kv);
-    auto load = [&](int k, float (&r)[2]) {
-      const int64_t row = r0 + k;
-      const float* vr = a.v + row * a.ld_v;
-      if (row < nodes_end) {
-        const int64_t n = b * a.Nmax + (row - b * a.Emax);
-        r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
-        r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];          // slot 6 | slot 8
-      } else {
-        r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
-        r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];          // slot 7 | slot 9
-      }
-    };
-    auto use = [&](int k, const float (&r)[2]) {
-      const bool diag = (r0 + k) < nodes_end;
-      stage_put<2>(L, stage, r);
-      float x[8], val[8];
-      slice8(L, stage, x); slice8(L, stage + 64, val);
-      const float p0 = phi_of(pre_x(L, x));
-      if (diag) kv_acc(kv[0], p0, val); else kv_acc(kv[1], p0, val);
-      slice8(L, stage + 32, x); slice8(L, stage + 96, val);
-      const float p1 = phi_of(pre_x(L, x));
-      if (diag) kv_acc(kv[2], p1, val); else kv_acc(kv[3], p1, val);
-    };
-    pipeline2<2>((int)(r1 - r0), load, use);
+    graphsum_rows<true>(L, a, stage, b, r0, rm, kv);
+    graphsum_rows<false>(L, a, stage, b, rm, r1, kv);
 #pragma unroll
     for (int s = 0; s < 4; ++s) kvg_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, kv[s]);
   }
@@ -362,88 +385,77 @@ __global__ void k_graph_reduce(const float* __restrict__ part, float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// node segments: wave per node.  Segment entries are fetched 64 at a time (entry id, row node, transposed
-// position, kind: one lane each), then walked with uniform readlane indices and the 2-deep row pipeline.
+// node segments: one wave per (node, PART).  PART p owns the two column sums of slots 2p, 2p+1
+//   p = 0: terms 1, 2  (values v0 | v1^T, applied to the node's own query; also the node-level graph terms 7, 8)
+//   p = 1: terms 3, 5  (values v2 | v3^T, applied to the entries of column n; also the entry-level graph terms 9, 10)
+//   p = 2: terms 4, 6  (values v4^T | v5, applied to the entries of ROW n)
+// so a wave carries 18 accumulators instead of 54 and three times as many waves hide the gather latency.
+// Segment entries come as packed records (plan): col_rec[p] = {entry row, row node, transposed row, kind},
+// row_rec[p] = entry row (off-diagonal) or ~entry row (diagonal); 64 records are fetched per block, one per lane,
+// and walked with wave-uniform readlane indices.
 // ------------------------------------------------------------------------------------------------
-struct SegBlock {
-  int32_t e, i, te, kd;
-};
+struct ColBlock { int32_t e, i, te, kd; };
 
-__device__ __forceinline__ SegBlock seg_block(const Lane& L, const A& a, const int32_t* __restrict__ perm, int32_t base,
-                                              int cnt, bool want_keys) {
-  SegBlock s{0, 0, -1, 0};
+__device__ __forceinline__ ColBlock col_block(const Lane& L, const A& a, int32_t base, int cnt) {
+  ColBlock s{0, 0, -1, 0};
   if (L.lane < cnt) {
-    s.e = perm[base + L.lane];
-    s.kd = a.kind[s.e];
-    if (want_keys) {
-      s.i = a.rown[s.e];
-      s.te = a.tpos[s.e];
-    }
+    const int4 r = reinterpret_cast<const int4*>(a.col_rec)[base + L.lane];
+    s.e = r.x; s.i = r.y; s.te = r.z; s.kd = r.w;
   }
   return s;
 }
 
-// six coalesced loads for one column-segment entry e = (i, j): key slots 0..5 of node i, value slots
-// {0 | 1t}, {2 | 3t}, {4t | 5} with the transposed slots (t) read from row te (zeros when absent)
-__device__ __forceinline__ void load_kv_rows(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[6]) {
-  const float* kp = a.h1 + (int64_t)i * a.ld_h1 + K1 * SLOT;
-  r[0] = kp[L.lane];
-  r[1] = kp[64 + L.lane];
-  r[2] = kp[128 + L.lane];
+// two coalesced loads for entry e = (i, j) of a column segment: key slots {2p, 2p+1} of node i and the value
+// slots {2p | 2p+1} where the transposed slot is read from row te (zeros when the transposed entry is absent)
+template <int P>
+__device__ __forceinline__ void load_kv2(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[2]) {
+  r[0] = a.h1[(int64_t)i * a.ld_h1 + (K1 + 2 * P) * SLOT + L.lane];
   const bool lo = L.lane < 32;
-  const int32_t ra = lo ? e : te, rb = lo ? te : e;
-  const float* va = a.v + (int64_t)(ra < 0 ? 0 : ra) * a.ld_v;
-  const float* vb = a.v + (int64_t)(rb < 0 ? 0 : rb) * a.ld_v;
-  const float x3 = va[L.lane], x4 = va[64 + L.lane], x5 = vb[128 + L.lane];
-  r[3] = ra < 0 ? 0.f : x3;
-  r[4] = ra < 0 ? 0.f : x4;
-  r[5] = rb < 0 ? 0.f : x5;
+  const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
+  const float x = a.v[(int64_t)(row < 0 ? 0 : row) * a.ld_v + 2 * P * SLOT + L.lane];
+  r[1] = row < 0 ? 0.f : x;
 }
 
-template <class F>
-__device__ __forceinline__ void for_col_entries_kv(const Lane& L, const A& a, float* stage, int32_t n,
-                                                   F per_entry) {
+template <int P, class F>
+__device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float* stage, int32_t n, F per_entry) {
   const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
   for (int32_t base = c0; base < c1; base += 64) {
     const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-    const SegBlock sb = seg_block(L, a, a.col_perm, base, cnt, true);
-    auto load = [&](int k, float (&r)[6]) { load_kv_rows(L, a, rl(sb.e, k), rl(sb.i, k), rl(sb.te, k), r); };
-    auto use = [&](int k, const float (&r)[6]) {
-      stage_put<6>(L, stage, r);
-      per_entry(rl(sb.e, k), rl(sb.te, k));
+    const ColBlock cb = col_block(L, a, base, cnt);
+    auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) { load_kv2<P>(L, a, rl(cb.e, k), rl(cb.i, k), rl(cb.te, k), r); };
+    auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+      stage_put<2>(L, stage, r);
+      per_entry(rl(cb.e, k), rl(cb.te, k));
     };
-    pipeline2<6>(cnt, load, use);
+    pipeline4<2>(cnt, load, use);
   }
 }
 
-__device__ __forceinline__ void colseg_accumulate(const Lane& L, const A& a, float* stage, int32_t n,
-                                                  float (&kv)[6][NC + 1]) {
-  kv_zero<6>(kv);
-  for_col_entries_kv(L, a, stage, n, [&](int32_t, int32_t) {
-#pragma unroll
-    for (int s = 0; s < 6; ++s) {
-      float x[8], val[8];
-      slice8(L, stage + s * SLOT, x);
-      slice8(L, stage + 192 + s * SLOT, val);
-      kv_acc(kv[s], phi_of(pre_x(L, x)), val);
-    }
+template <int P>
+__device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float* stage, int32_t n, float (&kv)[2][NC + 1]) {
+  kv_zero<2>(kv);
+  for_col_entries<P>(L, a, stage, n, [&](int32_t, int32_t) __attribute__((always_inline)) {
+    float x[8], val[8];
+    slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, val);
+    kv_acc(kv[0], phi_of(pre_x(L, x)), val);
+    slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
+    kv_acc(kv[1], phi_of(pre_x(L, x)), val);
   });
 }
 
-__global__ __launch_bounds__(256) void k_colseg_fwd(A a) {
+template <int P>
+__global__ __launch_bounds__(256) void k_seg_fwd(A a) {
   __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
-  const bool lo = L.lane < 32;
   for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * 4) {
     if (!a.nkind[n]) continue;
-    float kv[6][NC + 1];
-    colseg_accumulate(L, a, stage, (int32_t)n, kv);
-    const int64_t b = n / a.Nmax;
-    const float* kvg = a.kvg + b * 4 * (NC + 1) * 64;
-    float g0[NC + 1], g1[NC + 1];
-    // node queries: terms 1, 2 (column sums) and 7, 8 (graph sums) go to the node's diagonal row
-    {
+    float kv[2][NC + 1];
+    seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+    if (P == 0) {
+      // node queries: terms 1, 2 (column sums) and 7, 8 (graph sums) go to the node's diagonal row
+      const float* kvg = a.kvg + (n / a.Nmax) * 4 * (NC + 1) * 64;
+      float g0[NC + 1], g1[NC + 1];
       const float* q = a.h1 + n * a.ld_h1;
       float* o = a.att + (int64_t)a.diag_pos[n] * a.ld_att;
       float r[2] = {q[L.lane], q[64 + L.lane]};
@@ -457,60 +469,92 @@ __global__ __launch_bounds__(256) void k_colseg_fwd(A a) {
       slice8(L, stage + 3 * SLOT, x); apply_fwd_x(L, x, g1, o + 7 * SLOT);
       zero_slots(L, o + 2 * SLOT, 4);
       zero_slots(L, o + 8 * SLOT, 2);
-    }
-    kvg_load(L, kvg + 2 * (NC + 1) * 64, g0);
-    kvg_load(L, kvg + 3 * (NC + 1) * 64, g1);
-    // entries of column n: terms 3, 5 (this node's sums) and 9, 10 (graph sums)
-    {
+    } else if (P == 1) {
+      // entries of column n: terms 3, 5 (this node's sums) and 9, 10 (graph sums)
+      const float* kvg = a.kvg + (n / a.Nmax) * 4 * (NC + 1) * 64;
+      float g0[NC + 1], g1[NC + 1];
+      kvg_load(L, kvg + 2 * (NC + 1) * 64, g0);
+      kvg_load(L, kvg + 3 * (NC + 1) * 64, g1);
       const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
       for (int32_t base = c0; base < c1; base += 64) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-        const SegBlock sb = seg_block(L, a, a.col_perm, base, cnt, false);
-        auto load = [&](int k, float (&r)[2]) {
-          const float* q = a.h2 + (int64_t)rl(sb.e, k) * a.ld_h2;
+        const ColBlock cb = col_block(L, a, base, cnt);
+        auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+          const float* q = a.h2 + (int64_t)rl(cb.e, k) * a.ld_h2;
           r[0] = q[L.lane];               // query slots 0, 1
           r[1] = q[4 * SLOT + L.lane];    // query slots 4, 5
         };
-        auto use = [&](int k, const float (&r)[2]) {
-          if (rl(sb.kd, k) != 2) return;
-          float* o = a.att + (int64_t)rl(sb.e, k) * a.ld_att;
+        auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+          if (rl(cb.kd, k) != 2) return;
+          float* o = a.att + (int64_t)rl(cb.e, k) * a.ld_att;
           stage_put<2>(L, stage, r);
           float x[8];
-          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[2], o + 2 * SLOT);
-          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[3], o + 4 * SLOT);
+          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[0], o + 2 * SLOT);
+          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[1], o + 4 * SLOT);
           slice8(L, stage + 2 * SLOT, x); apply_fwd_x(L, x, g0, o + 8 * SLOT);
           slice8(L, stage + 3 * SLOT, x); apply_fwd_x(L, x, g1, o + 9 * SLOT);
           o[L.lane] = 0.f;                 // terms 1, 2 live on the diagonal only
           o[6 * SLOT + L.lane] = 0.f;      // terms 7, 8 too
         };
-        pipeline2<2>(cnt, load, use);
+        pipeline4<2>(cnt, load, use);
       }
-    }
-    // entries of row n: terms 4, 6 read the sums of their ROW node
-    {
+    } else {
+      // entries of row n: terms 4, 6 read the sums of their ROW node
       const int32_t c0 = a.row_ptr[n], c1 = a.row_ptr[n + 1];
       for (int32_t base = c0; base < c1; base += 64) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-        const SegBlock sb = seg_block(L, a, a.row_perm, base, cnt, false);
-        auto load = [&](int k, float (&r)[1]) { r[0] = a.h2[(int64_t)rl(sb.e, k) * a.ld_h2 + 2 * SLOT + L.lane]; };
-        auto use = [&](int k, const float (&r)[1]) {
-          if (rl(sb.kd, k) != 2) return;
-          float* o = a.att + (int64_t)rl(sb.e, k) * a.ld_att;
+        const int32_t rec = L.lane < cnt ? a.row_rec[base + L.lane] : -1;
+        auto load = [&](int k, float (&r)[1]) __attribute__((always_inline)) {
+          const int32_t e = rl(rec, k);
+          r[0] = a.h2[(int64_t)(e < 0 ? ~e : e) * a.ld_h2 + 2 * SLOT + L.lane];
+        };
+        auto use = [&](int k, const float (&r)[1]) __attribute__((always_inline)) {
+          const int32_t e = rl(rec, k);
+          if (e < 0) return;
+          float* o = a.att + (int64_t)e * a.ld_att;
           stage_put<1>(L, stage, r);
           float x[8];
-          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[4], o + 3 * SLOT);
-          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[5], o + 5 * SLOT);
+          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[0], o + 3 * SLOT);
+          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[1], o + 5 * SLOT);
         };
-        pipeline2<1>(cnt, load, use);
+        pipeline4<1>(cnt, load, use);
       }
     }
-    (void)lo;
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // per-graph terms (backward): (1) query side + dKVg partials, (2) key/value side
 // ------------------------------------------------------------------------------------------------
+template <bool DIAG>
+__device__ __forceinline__ void graph_apply_bwd_rows(const Lane& L, const A& a, float* stage, int64_t b, int64_t ra,
+                                                     int64_t rb, const float (&kv)[4][NC + 1], float (&dkv)[4][NC + 1]) {
+  auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+    const int64_t row = ra + k;
+    const float* g = a.datt + row * a.ld_datt;
+    if (DIAG) {
+      const int64_t n = b * a.Nmax + (row - b * a.Emax);
+      r[0] = a.h1[n * a.ld_h1 + 2 * SLOT + L.lane];     // node query slots 2, 3
+      r[1] = g[6 * SLOT + L.lane];                       // d term 7, 8
+    } else {
+      r[0] = a.h2[row * a.ld_h2 + 4 * SLOT + L.lane];   // entry query slots 4, 5
+      r[1] = g[8 * SLOT + L.lane];                       // d term 9, 10
+    }
+  };
+  auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+    const int64_t row = ra + k;
+    stage_put<2>(L, stage, r);
+    float x[8], g[8];
+    float* dq = DIAG ? a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 2 * SLOT
+                     : a.dh2 + row * a.ld_dh2 + 4 * SLOT;
+    slice8(L, stage, x); slice8(L, stage + 64, g);
+    apply_bwd_x(L, x, kv[DIAG ? 0 : 2], g, dq, dkv[DIAG ? 0 : 2]);
+    slice8(L, stage + 32, x); slice8(L, stage + 96, g);
+    apply_bwd_x(L, x, kv[DIAG ? 1 : 3], g, dq + SLOT, dkv[DIAG ? 1 : 3]);
+  };
+  pipeline4<2>((int)(rb - ra), load, use);
+}
+
 __global__ __launch_bounds__(256) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
   __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
@@ -520,35 +564,13 @@ __global__ __launch_bounds__(256) void k_graph_apply_bwd(A a, float* __restrict_
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
+    const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
     float kv[4][NC + 1], dkv[4][NC + 1];
 #pragma unroll
     for (int s = 0; s < 4; ++s) kvg_load(L, a.kvg + ((int64_t)b * 4 + s) * (NC + 1) * 64, kv[s]);
     kv_zero<4>(dkv);
-    auto load = [&](int k, float (&r)[2]) {
-      const int64_t row = r0 + k;
-      const float* g = a.datt + row * a.ld_datt;
-      if (row < nodes_end) {
-        const int64_t n = b * a.Nmax + (row - b * a.Emax);
-        r[0] = a.h1[n * a.ld_h1 + 2 * SLOT + L.lane];     // node query slots 2, 3
-        r[1] = g[6 * SLOT + L.lane];                       // d term 7, 8
-      } else {
-        r[0] = a.h2[row * a.ld_h2 + 4 * SLOT + L.lane];   // entry query slots 4, 5
-        r[1] = g[8 * SLOT + L.lane];                       // d term 9, 10
-      }
-    };
-    auto use = [&](int k, const float (&r)[2]) {
-      const int64_t row = r0 + k;
-      const bool diag = row < nodes_end;
-      stage_put<2>(L, stage, r);
-      float x[8], g[8];
-      float* dq = diag ? a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 2 * SLOT
-                       : a.dh2 + row * a.ld_dh2 + 4 * SLOT;
-      slice8(L, stage, x); slice8(L, stage + 64, g);
-      if (diag) apply_bwd_x(L, x, kv[0], g, dq, dkv[0]); else apply_bwd_x(L, x, kv[2], g, dq, dkv[2]);
-      slice8(L, stage + 32, x); slice8(L, stage + 96, g);
-      if (diag) apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]); else apply_bwd_x(L, x, kv[3], g, dq + SLOT, dkv[3]);
-    };
-    pipeline2<2>((int)(r1 - r0), load, use);
+    graph_apply_bwd_rows<true>(L, a, stage, b, r0, rm, kv, dkv);
+    graph_apply_bwd_rows<false>(L, a, stage, b, rm, r1, kv, dkv);
 #pragma unroll
     for (int s = 0; s < 4; ++s) kvg_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, dkv[s]);
   }
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(256) void k_graphsum_bwd(A a) {
     float d[4][NC + 1];
 #pragma unroll
     for (int s = 0; s < 4; ++s) kvg_load(L, dkvg + s * (NC + 1) * 64, d[s]);
-    auto load = [&](int k, float (&r)[3]) {
+    auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
       const int64_t row = r0 + k;
       const float* vr = a.v + row * a.ld_v;
       if (row < nodes_end) {
@@ -585,7 +607,7 @@ __global__ __launch_bounds__(256) void k_graphsum_bwd(A a) {
       }
       r[2] = (a.dout && L.lane < a.D) ? a.dout[row * a.ld_dout + L.lane] : 0.f;
     };
-    auto use = [&](int k, const float (&r)[3]) {
+    auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
       const int64_t row = r0 + k;
       const bool diag = row < nodes_end;
       stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
@@ -611,24 +633,25 @@ __global__ __launch_bounds__(256) void k_graphsum_bwd(A a) {
       if (L.lane < a.D) dh2r[8 * SLOT + L.lane] = r[2];
       for (int i = 64 + L.lane; i < a.D; i += 64) dh2r[8 * SLOT + i] = a.dout ? a.dout[row * a.ld_dout + i] : 0.f;
     };
-    pipeline2<3>((int)(r1 - r0), load, use);
+    pipeline4<3>((int)(r1 - r0), load, use);
   }
 }
 
 // ------------------------------------------------------------------------------------------------
-// node segments (backward): wave per node
+// node segments (backward): one wave per (node, part), same split as the forward
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_colseg_bwd(A a) {
+template <int P>
+__global__ __launch_bounds__(256) void k_seg_bwd(A a) {
   __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
   for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * 4) {
     if (!a.nkind[n]) continue;
-    float kv[6][NC + 1], dkv[6][NC + 1];
-    colseg_accumulate(L, a, stage, (int32_t)n, kv);
-    kv_zero<6>(dkv);
-    {  // node queries (terms 1, 2)
+    float kv[2][NC + 1], dkv[2][NC + 1];
+    seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+    kv_zero<2>(dkv);
+    if (P == 0) {  // node queries (terms 1, 2)
       const int64_t dr = a.diag_pos[n];
       float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[dr * a.ld_datt + L.lane]};
       float* dq = a.dh1 + n * a.ld_dh1;
@@ -636,68 +659,64 @@ __global__ __launch_bounds__(256) void k_colseg_bwd(A a) {
       float x[8], g[8];
       slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
       slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
-    }
-    {  // entries of column n (terms 3, 5)
+    } else if (P == 1) {  // entries of column n (terms 3, 5)
       const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
       for (int32_t base = c0; base < c1; base += 64) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-        const SegBlock sb = seg_block(L, a, a.col_perm, base, cnt, false);
-        auto load = [&](int k, float (&r)[2]) {
-          const int64_t e = rl(sb.e, k);
+        const ColBlock cb = col_block(L, a, base, cnt);
+        auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+          const int64_t e = rl(cb.e, k);
           r[0] = a.h2[e * a.ld_h2 + L.lane];                                      // query slots 0, 1
           r[1] = a.datt[e * a.ld_datt + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
         };
-        auto use = [&](int k, const float (&r)[2]) {
-          if (rl(sb.kd, k) != 2) return;
-          float* dq = a.dh2 + (int64_t)rl(sb.e, k) * a.ld_dh2;
+        auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+          if (rl(cb.kd, k) != 2) return;
+          float* dq = a.dh2 + (int64_t)rl(cb.e, k) * a.ld_dh2;
           stage_put<2>(L, stage, r);
           float x[8], g[8];
-          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[2], g, dq, dkv[2]);
-          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[3], g, dq + SLOT, dkv[3]);
+          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
+          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
         };
-        pipeline2<2>(cnt, load, use);
+        pipeline4<2>(cnt, load, use);
       }
-    }
-    {  // entries of row n (terms 4, 6)
+    } else {  // entries of row n (terms 4, 6)
       const int32_t c0 = a.row_ptr[n], c1 = a.row_ptr[n + 1];
       for (int32_t base = c0; base < c1; base += 64) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-        const SegBlock sb = seg_block(L, a, a.row_perm, base, cnt, false);
-        auto load = [&](int k, float (&r)[2]) {
-          const int64_t e = rl(sb.e, k);
+        const int32_t rec = L.lane < cnt ? a.row_rec[base + L.lane] : -1;
+        auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+          const int32_t e_ = rl(rec, k);
+          const int64_t e = e_ < 0 ? ~e_ : e_;
           r[0] = a.h2[e * a.ld_h2 + 2 * SLOT + L.lane];                            // query slots 2, 3
           r[1] = a.datt[e * a.ld_datt + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
         };
-        auto use = [&](int k, const float (&r)[2]) {
-          if (rl(sb.kd, k) != 2) return;
-          float* dq = a.dh2 + (int64_t)rl(sb.e, k) * a.ld_dh2 + 2 * SLOT;
+        auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+          const int32_t e = rl(rec, k);
+          if (e < 0) return;
+          float* dq = a.dh2 + (int64_t)e * a.ld_dh2 + 2 * SLOT;
           stage_put<2>(L, stage, r);
           float x[8], g[8];
-          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[4], g, dq, dkv[4]);
-          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[5], g, dq + SLOT, dkv[5]);
+          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
+          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
         };
-        pipeline2<2>(cnt, load, use);
+        pipeline4<2>(cnt, load, use);
       }
     }
-    // key / value side of the six column sums: dV to row e (slots 0,2,5) or its transposed row (slots 1,3,4),
-    // d(raw key) contributions to ck[e] (summed per row node afterwards)
-    for_col_entries_kv(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te) {
+    // key / value side of this part's two column sums: dV of the plain slot goes to row e, dV of the transposed
+    // slot to row te; d(raw key) contributions go to ck[e] (summed per row node afterwards)
+    for_col_entries<P>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te) __attribute__((always_inline)) {
       float* dve = a.dv + (int64_t)e * a.ld_dv;
       float* dvt = te >= 0 ? a.dv + (int64_t)te * a.ld_dv : nullptr;
-      float* ck = a.ck + (int64_t)e * (6 * SLOT);
-#pragma unroll
-      for (int s = 0; s < 6; ++s) {
-        float x[8], val[8];
-        slice8(L, stage + s * SLOT, x);
-        slice8(L, stage + 192 + s * SLOT, val);
-        const bool tr = (s == 1 || s == 3 || s == 4);
-        float* dvp = tr ? (dvt ? dvt + s * SLOT : nullptr) : dve + s * SLOT;
-        kv_bwd_x(L, x, val, dkv[s], dvp, ck + s * SLOT);
-      }
-      if (te < 0) {  // no transposed partner writes these slots of row e
-        if (lo) dve[1 * SLOT + L.lane] = 0.f;
-        dve[3 * SLOT + L.lane] = 0.f;
-      }
+      float* ck = a.ck + (int64_t)e * (6 * SLOT) + 2 * P * SLOT;
+      constexpr int S0 = 2 * P, S1 = 2 * P + 1;
+      float* d0 = (P == 2) ? (dvt ? dvt + S0 * SLOT : nullptr) : dve + S0 * SLOT;
+      float* d1 = (P == 2) ? dve + S1 * SLOT : (dvt ? dvt + S1 * SLOT : nullptr);
+      float x[8], val[8];
+      slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, val);
+      kv_bwd_x(L, x, val, dkv[0], d0, ck);
+      slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
+      kv_bwd_x(L, x, val, dkv[1], d1, ck + SLOT);
+      if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
     });
   }
 }
@@ -707,7 +726,7 @@ int check_args(const A* a) {
   if (a->H != NH || a->m != NM || a->d_head != DH || a->c != NC) return HOTK_EUNSUPPORTED;
   if (a->B < 0 || a->Emax < 0 || a->Nmax < 0 || a->R != a->B * a->Emax || a->Nn != a->B * a->Nmax) return HOTK_EINVAL;
   if (!a->h1 || !a->h2 || !a->v || !a->proj || !a->kind || !a->nkind || !a->rown || !a->coln || !a->tpos ||
-      !a->diag_pos || !a->col_ptr || !a->col_perm || !a->row_ptr || !a->row_perm || !a->n_entries || !a->n_nodes)
+      !a->diag_pos || !a->col_ptr || !a->col_perm || !a->row_ptr || !a->row_perm || !a->n_entries || !a->n_nodes || !a->col_rec || !a->row_rec)
     return HOTK_EINVAL;
   if (a->ld_h1 < 12 * SLOT || a->ld_h2 < 8 * SLOT || a->ld_v < 10 * SLOT) return HOTK_EINVAL;
   // 16-byte vector loads of 8-float head slices
@@ -717,8 +736,8 @@ int check_args(const A* a) {
 }
 
 void chunking(const A* a, int* cpg, int* rows) {
-  int64_t c = (a->Emax + 255) / 256;
-  if (c > 1024) c = 1024;
+  int64_t c = (a->Emax + 63) / 64;
+  if (c > 4096) c = 4096;
   if (c < 1) c = 1;
   *cpg = (int)c;
   *rows = (int)((a->Emax + c - 1) / c);
@@ -728,8 +747,8 @@ void chunking(const A* a, int* cpg, int* rows) {
 
 extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes) {
   HOTK_CHECK_ARG(bytes && B >= 0 && Emax >= 0);
-  int64_t c = (Emax + 255) / 256;
-  if (c > 1024) c = 1024;
+  int64_t c = (Emax + 63) / 64;
+  if (c > 4096) c = 4096;
   if (c < 1) c = 1;
   *bytes = (size_t)B * c * 4 * (NC + 1) * 64 * sizeof(float);
   return HOTK_OK;
@@ -747,12 +766,15 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
   float* part = cpg > 1 ? (float*)workspace : a->kvg;
-  unsigned g1 = hotk_grid(a->B * cpg, 4, 256 * 16);
+  unsigned g1 = hotk_grid((int64_t)a->B * cpg, 4, 256 * 32);
   hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(256), 0, st, *a, part, cpg, rows);
   if (cpg > 1)
     hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->kvg,
                        a->B, cpg);
-  hipLaunchKernelGGL(k_colseg_fwd, dim3(hotk_grid(a->Nn, 4, 256 * 32)), dim3(256), 0, st, *a);
+  const dim3 gseg(hotk_grid(a->Nn, 4, 256 * 32));
+  hipLaunchKernelGGL(k_seg_fwd<1>, gseg, dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_fwd<2>, gseg, dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_fwd<0>, gseg, dim3(256), 0, st, *a);
   return hotk_launch_status();
 }
 
@@ -772,11 +794,14 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
   float* part = cpg > 1 ? (float*)workspace : a->dkvg;
-  hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid(a->B * cpg, 4, 256 * 16)), dim3(256), 0, st, *a, part, cpg, rows);
+  hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, 4, 256 * 32)), dim3(256), 0, st, *a, part, cpg, rows);
   if (cpg > 1)
     hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->dkvg,
                        a->B, cpg);
   hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->R, 4, 256 * 32)), dim3(256), 0, st, *a);
-  hipLaunchKernelGGL(k_colseg_bwd, dim3(hotk_grid(a->Nn, 4, 256 * 32)), dim3(256), 0, st, *a);
+  const dim3 gseg(hotk_grid(a->Nn, 4, 256 * 32));
+  hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_bwd<0>, gseg, dim3(256), 0, st, *a);
   return hotk_launch_status();
 }

@@ -121,6 +121,44 @@ __global__ __launch_bounds__(256) void k_bias_grad_rows(const float* __restrict_
   }
 }
 
+// float4 variant: thread = (channel vector cv, row lane ty); TY rows are read in parallel, each row as whole
+// contiguous pieces; the TY partial sums meet in LDS and leave as one atomic per channel and block
+__global__ __launch_bounds__(256) void k_bias_grad_rows4(const float* __restrict__ dy, int64_t ld,
+                                                         const uint8_t* __restrict__ kind, float* __restrict__ db_off,
+                                                         float* __restrict__ db_diag, int64_t n, int C4, int TY,
+                                                         int64_t rows_per_block) {
+  __shared__ float4 red[2][256];
+  const int cv = threadIdx.x % C4, ty = threadIdx.x / C4;
+  float4 a_off = make_float4(0.f, 0.f, 0.f, 0.f), a_diag = a_off;
+  int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
+  if (r1 > n) r1 = n;
+  if (ty < TY) {
+    for (int64_t r = r0 + ty; r < r1; r += TY) {
+      const uint8_t kd = kind[r];
+      if (kd == 0) continue;
+      const float4 v = *reinterpret_cast<const float4*>(dy + r * ld + 4 * cv);
+      if (kd == 2) a_off = vadd(a_off, v); else a_diag = vadd(a_diag, v);
+    }
+  }
+  red[0][threadIdx.x] = a_off;
+  red[1][threadIdx.x] = a_diag;
+  __syncthreads();
+  if (ty == 0) {
+    for (int k = 1; k < TY; ++k) {
+      a_off = vadd(a_off, red[0][k * C4 + cv]);
+      a_diag = vadd(a_diag, red[1][k * C4 + cv]);
+    }
+    if (db_off) {
+      atomicAdd(db_off + 4 * cv + 0, a_off.x); atomicAdd(db_off + 4 * cv + 1, a_off.y);
+      atomicAdd(db_off + 4 * cv + 2, a_off.z); atomicAdd(db_off + 4 * cv + 3, a_off.w);
+    }
+    if (db_diag) {
+      atomicAdd(db_diag + 4 * cv + 0, a_diag.x); atomicAdd(db_diag + 4 * cv + 1, a_diag.y);
+      atomicAdd(db_diag + 4 * cv + 2, a_diag.z); atomicAdd(db_diag + 4 * cv + 3, a_diag.w);
+    }
+  }
+}
+
 // ------------------------------------------------------------------ order-2 'light' basis
 template <int V>
 __global__ void k_basis22_light_fwd(const float* __restrict__ x, int64_t ld_x, const uint8_t* __restrict__ kind,
@@ -279,6 +317,15 @@ extern "C" int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* k
   if (n == 0 || C == 0) return HOTK_OK;
   HOTK_CHECK_ARG(dy && kind);
   hipStream_t st = (hipStream_t)stream;
+  if (C % 4 == 0 && C / 4 <= 256 && ld % 4 == 0 && hotk_aligned16(dy)) {
+    const int C4 = (int)(C / 4), TY = 256 / C4;
+    int64_t nb = hotk_grid(n, 512, 4096);
+    int64_t rpb = (n + nb - 1) / nb;
+    nb = (n + rpb - 1) / rpb;
+    hipLaunchKernelGGL(k_bias_grad_rows4, dim3((unsigned)nb), dim3(256), 0, st, dy, ld, kind, db_off, db_diag, n, C4, TY,
+                       rpb);
+    return hotk_launch_status();
+  }
   int64_t blocks = hotk_grid(n, 64, 2048);  // >= 64 rows per block
   int64_t rpb = (n + blocks - 1) / blocks;
   blocks = (n + rpb - 1) / rpb;

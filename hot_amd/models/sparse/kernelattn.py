@@ -118,7 +118,8 @@ class KernelSelfAttn(nn.Module):
         h_1 = self.fc_1(G)                      # [B, N, 12 dqk]: 4 query slots, 8 key slots
         h_2 = self.fc_2(G)                      # [B, |E|, 8 dqk + D]: 6 query slots, 2 key slots, skip path
         if self._fused_ok():
-            v = self.fc_v(G.values)             # padding rows are ignored by the kernels: no masking pass
+            # padding rows are ignored by the kernels: no masking pass
+            v = ops.RowsMatmul.apply(G.values, self.fc_v.weight.t(), self.fc_v.bias)   # [R, 10 dv]
             out = ops.AttnCore22.apply(h_1.values, h_2.values, v, self.feature_map.feature_map.projection_matrix,
                                        self.fc_o.weight, self.fc_o.bias, G.plan)
             return batch_like(G, out, skip_masking=True)

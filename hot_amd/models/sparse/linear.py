@@ -39,22 +39,22 @@ class _Weight(nn.Module):
         if isinstance(G, B):
             assert G.order == self.ord_in
         if key == (0, 0):
-            return None, G @ self.weight
+            return None, ops.RowsMatmul.apply(G, self.weight, None)
         if key == (1, 2):
             raise NotImplementedError('Sparse set-to-graph is inefficient; use a dense layer')
         if key == (1, 0):
-            return None, basis.pool_1_to_0(G, self.normalize) @ self.weight
+            return None, ops.RowsMatmul.apply(basis.pool_1_to_0(G, self.normalize), self.weight, None)
         if key == (2, 0):
-            return None, basis.pool_2_to_0(G, self.normalize) @ self.weight
+            return None, ops.RowsMatmul.apply(basis.pool_2_to_0(G, self.normalize), self.weight, None)
         if key == (1, 1):
             V = G.values if self.cfg == 'light' else basis.basis_1_to_1(G, self.normalize)
-            return G, V @ self.weight
+            return G, ops.RowsMatmul.apply(V, self.weight, None)
         if key == (2, 1):
             dG = d(G)
             V = dG.values if self.cfg == 'light' else basis.basis_2_to_1(G, dG, self.normalize)
-            return dG, V @ self.weight
+            return dG, ops.RowsMatmul.apply(V, self.weight, None)
         V = ops.Basis22Light.apply(G.values, G.plan) if self.cfg == 'light' else basis.basis_2_to_2(G, self.normalize)
-        return G, V @ self.weight
+        return G, ops.RowsMatmul.apply(V, self.weight, None)
 
 
 class _Bias(nn.Module):
@@ -88,7 +88,8 @@ class Linear(nn.Module):
         plan = H.plan
         if H.order == 2:
             # bias[0] on off-diagonal rows, bias[1] on diagonal rows, padding zeroed (linear.py:297-306,345-346)
-            y = ops.BiasMask.apply(y, plan.kind, None if bias is None else bias[0], None if bias is None else bias[1])
+            y = ops.BiasMask.apply(y, plan.kind, None if bias is None else bias[0], None if bias is None else bias[1],
+                                   plan.Ev == plan.R)
         else:
-            y = ops.BiasMask.apply(y, plan.nkind, None, None if bias is None else bias[0])
-        return batch_like(H, y, skip_masking=True)
+            y = ops.BiasMask.apply(y, plan.nkind, None, None if bias is None else bias[0], sum(H.n_nodes) == plan.Nn)
+        return batch_like(H, y.view(*H.values.shape[:-1], y.size(-1)), skip_masking=True)

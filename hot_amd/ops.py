@@ -229,13 +229,14 @@ class BiasMask(Function):
     Stands in for _Bias._1/_2 followed by Linear's apply_mask(0) (models/sparse/linear.py:293-306,345-346)."""
 
     @staticmethod
-    def forward(ctx, y, kind, b_off, b_diag):
+    def forward(ctx, y, kind, b_off, b_diag, no_pad=False):
         ys, ld, n, C = rows2d(y)
         assert ys.data_ptr() == y.data_ptr(), 'BiasMask expects a row-contiguous tensor'
         call('hotk_bias_mask_rows', 8 * n * C, p(ys), ld, p(kind), p(b_off), p(b_diag), n, C)
         ctx.mark_dirty(y)
         ctx.save_for_backward(kind)
         ctx.has = (b_off is not None, b_diag is not None)
+        ctx.no_pad = no_pad
         return y
 
     @staticmethod
@@ -246,7 +247,7 @@ class BiasMask(Function):
         db_diag = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[1] else None
         if db_off is not None or db_diag is not None:
             call('hotk_bias_grad_rows', 4 * n * C, p(gs), ld, p(kind), p(db_off), p(db_diag), n, C)
-        return mask_rows(g, kind, KEEP_VALID, 0.0), None, db_off, db_diag
+        return (g if ctx.no_pad else mask_rows(g, kind, KEEP_VALID, 0.0)), None, db_off, db_diag, None
 
 
 class KernelAttn(Function):
@@ -314,6 +315,45 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
+def wgrad(A, B):
+    """A^T @ B for tall operands A [R,K], B [R,N] (a reduction over R rows into a small K x N result).
+    A single library GEMM has only K*N/tile workgroups to run on, so the row dimension is split into S batches
+    (torch.bmm -> rocBLAS/hipBLASLt batched GEMM) whose partial products are summed: split-K over 256 CUs."""
+    R = A.size(0)
+    if R < (1 << 16):
+        return A.t() @ B
+    S = 256
+    rs = R // S
+    main = rs * S
+    out = torch.bmm(A[:main].view(S, rs, A.size(1)).transpose(1, 2), B[:main].view(S, rs, B.size(1))).sum(0)
+    if main < R:
+        out = out + A[main:].t() @ B[main:]
+    return out
+
+
+class RowsMatmul(Function):
+    """y = x @ W (+ b) over rows [R,K] x [K,N]; backward uses the split-K weight gradient.  The dense projections
+    stay library GEMMs (models/sparse/linear.py:46-48, kernelattn.py:65-72)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        x2 = x.reshape(-1, x.size(-1))
+        # 2-D result on purpose (a fresh tensor, not a view): callers may finish it in place (BiasMask)
+        return torch.addmm(b, x2, w) if b is not None else x2 @ w
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w = ctx.saved_tensors
+        g2 = g.reshape(-1, g.size(-1))
+        x2 = x.reshape(-1, x.size(-1))
+        dx = (g2 @ w.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = wgrad(x2, g2) if ctx.needs_input_grad[1] else None
+        db = g2.sum(0) if ctx.has_b and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
 class AttnCore22(Function):
     """out = skip + mask(fc_o(cat(att_1..att_10))) for KernelSelfAttn(2,2) at the fused shape, straight from the raw
     projections h1 = fc_1(G), h2 = fc_2(G), v = fc_v(values): the feature maps, the six per-node and four per-graph
@@ -330,6 +370,8 @@ class AttnCore22(Function):
             setattr(a, n, getattr(plan, n).data_ptr())
         a.n_entries = plan.n_entries_dev.data_ptr()
         a.n_nodes = plan.n_nodes_dev.data_ptr()
+        col_rec, row_rec = plan.records()
+        a.col_rec, a.row_rec = col_rec.data_ptr(), row_rec.data_ptr()
         a.h1, a.ld_h1 = h1.data_ptr(), h1.size(-1)
         a.h2, a.ld_h2 = h2.data_ptr(), h2.size(-1)
         a.v, a.ld_v = v.data_ptr(), v.size(-1)
@@ -360,7 +402,8 @@ class AttnCore22(Function):
         call('hotk_attn22_forward', 4 * plan.Ev * (8 * 32 + 10 * 32 + 10 * 32) + 4 * plan.Nn * 384,
              byref(a), p(ws), nws)
         y = torch.addmm(b_o, att, w_o.t())
-        y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
+        if padded:
+            y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
         out = y.add_(h2.view(plan.R, -1)[:, 256:]).view(*h2.shape[:-1], D)
         ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg)
         ctx.plan = plan
@@ -373,9 +416,10 @@ class AttnCore22(Function):
         dev = h2.device
         D = w_o.size(0)
         d_out = d_out.contiguous().view(plan.R, D)
-        dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0)
+        padded = plan.Ev != plan.R
+        dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
         datt = dy @ w_o
-        dw_o = dy.t() @ att
+        dw_o = wgrad(dy, att)
         db_o = dy.sum(0)
         padded = plan.Ev != plan.R
         # padding rows of dh1 / dh2 are never read (the BiasMask backward of fc_1 / fc_2 selects valid rows only);

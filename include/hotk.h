@@ -183,6 +183,8 @@ typedef struct hotk_attn22_args {
   int32_t H, m, d_head, c;
   const uint8_t *kind, *nkind;
   const int32_t *rown, *coln, *tpos, *diag_pos, *col_ptr, *col_perm, *row_ptr, *row_perm, *n_entries, *n_nodes;
+  const int32_t *col_rec; /* [Ev][4] = {entry row, row node, transposed row or -1, kind} in column-CSR order */
+  const int32_t *row_rec; /* [Ev] entry row in row-CSR order, bit-complemented for diagonal entries */
   const float* h1; int64_t ld_h1;
   const float* h2; int64_t ld_h2;
   const float* v; int64_t ld_v;
