@@ -114,6 +114,7 @@ def main():
 
     from hot_amd import _lib
     from hot_amd.batch.sparse import batch_like
+    from hot_amd.dist import allreduce_gradients, max_over_ranks
 
     n_graphs = max(1, int(round(args.entries / ENTRIES_PER_GRAPH)))
     G = make_inputs(n_graphs, device, seed=1234 + rank)
@@ -128,8 +129,7 @@ def main():
         out = layer(batch_like(G, x, skip_masking=True))
         out.values.sum().backward()
         if dist is not None:
-            flat = torch.cat([p.grad.reshape(-1) for p in params])
-            dist.all_reduce(flat)
+            allreduce_gradients(params)
         for p in params:
             p.grad = None
 
@@ -159,10 +159,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timed = _lib.timing_end()
-    if dist is not None:
-        tmax = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(elapsed, device)
     total_entries = n_entries * world
     value = total_entries * args.steps / elapsed
 
