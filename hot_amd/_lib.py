@@ -10,7 +10,7 @@ from ctypes import c_int, c_int64, c_size_t, c_uint, c_void_p, c_float
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libhotk.so')
+LIB_PATH = os.environ.get('HOTK_LIB') or os.path.join(_HERE, 'libhotk.so')   # HOTK_LIB: A/B builds of the same ABI
 
 KEEP_PAD, KEEP_DIAG, KEEP_OFFDIAG = 1, 2, 4
 KEEP_VALID = KEEP_DIAG | KEEP_OFFDIAG

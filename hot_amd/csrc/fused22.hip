@@ -310,6 +310,15 @@ __device__ __forceinline__ void kv_zero(float (&kv)[S][NC + 1]) {
 // v slots 0..5 feed the node-segment terms, 6..9 the per-graph terms
 constexpr int K1 = 4, K2 = 6;
 constexpr int STAGE_FLOATS = 6 * 64;
+constexpr int WPB = 1;            // waves per block: single-wave blocks release their slot as soon as the wave ends
+constexpr int TPB = 64 * WPB;
+#ifndef HOTK_GRID_CAP
+#define HOTK_GRID_CAP (1 << 20)
+#endif
+constexpr int64_t GRID_CAP = HOTK_GRID_CAP;
+#ifndef HOTK_MINW
+#define HOTK_MINW 1
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // per-graph sums (forward): wave per (graph, row chunk); rows are consecutive, two coalesced loads per row
@@ -354,12 +363,12 @@ __device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* 
   pipeline4<2>((int)(rb - ra), load, use);
 }
 
-__global__ __launch_bounds__(256) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
-  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+__global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+  for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];   // rows below are the diagonal (layout invariant)
@@ -412,8 +421,18 @@ __device__ __forceinline__ void load_kv2(const Lane& L, const A& a, int32_t e, i
   r[0] = a.h1[(int64_t)i * a.ld_h1 + (K1 + 2 * P) * SLOT + L.lane];
   const bool lo = L.lane < 32;
   const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
-  const float x = a.v[(int64_t)(row < 0 ? 0 : row) * a.ld_v + 2 * P * SLOT + L.lane];
-  r[1] = row < 0 ? 0.f : x;
+  // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time
+  // (t_scale): selecting on the loaded value here would make the prefetch synchronous
+  r[1] = a.v[(int64_t)(row < 0 ? e : row) * a.ld_v + 2 * P * SLOT + L.lane];
+}
+
+// KV accumulate whose value channels are scaled by s (0 when the transposed entry is absent): the normaliser
+// channel still counts the key (kernelattncoef.py:103-122 sums keys over every entry of the column)
+__device__ __forceinline__ void kv_acc_scaled(float (&kv)[NC + 1], float phi, const float (&val)[NC], float s) {
+  const float ps = phi * s;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) kv[c] = fmaf(ps, val[c], kv[c]);
+  kv[NC] += phi;
 }
 
 template <int P, class F>
@@ -434,21 +453,24 @@ __device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float
 template <int P>
 __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float* stage, int32_t n, float (&kv)[2][NC + 1]) {
   kv_zero<2>(kv);
-  for_col_entries<P>(L, a, stage, n, [&](int32_t, int32_t) __attribute__((always_inline)) {
+  for_col_entries<P>(L, a, stage, n, [&](int32_t, int32_t te) __attribute__((always_inline)) {
     float x[8], val[8];
+    const float ts = te < 0 ? 0.f : 1.f;   // the transposed-value slot is slot 0 for P == 2, slot 1 otherwise
     slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, val);
-    kv_acc(kv[0], phi_of(pre_x(L, x)), val);
+    if (P == 2) kv_acc_scaled(kv[0], phi_of(pre_x(L, x)), val, ts);
+    else kv_acc(kv[0], phi_of(pre_x(L, x)), val);
     slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
-    kv_acc(kv[1], phi_of(pre_x(L, x)), val);
+    if (P == 2) kv_acc(kv[1], phi_of(pre_x(L, x)), val);
+    else kv_acc_scaled(kv[1], phi_of(pre_x(L, x)), val, ts);
   });
 }
 
 template <int P>
-__global__ __launch_bounds__(256) void k_seg_fwd(A a) {
-  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+__global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_fwd(A a) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
-  for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * 4) {
+  for (int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float kv[2][NC + 1];
     seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
@@ -555,12 +577,12 @@ __device__ __forceinline__ void graph_apply_bwd_rows(const Lane& L, const A& a, 
   pipeline4<2>((int)(rb - ra), load, use);
 }
 
-__global__ __launch_bounds__(256) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
-  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+__global__ __launch_bounds__(TPB, HOTK_MINW) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+  for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
@@ -578,14 +600,14 @@ __global__ __launch_bounds__(256) void k_graph_apply_bwd(A a, float* __restrict_
 
 // wave per chunk of 16 consecutive rows of one graph
 constexpr int GB_ROWS = 16;
-__global__ __launch_bounds__(256) void k_graphsum_bwd(A a) {
-  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+__global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_bwd(A a) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
   const int64_t cpg = (a.Emax + GB_ROWS - 1) / GB_ROWS;
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * 4) {
+  for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
     int64_t b, r0, r1;
     chunk_rows(a, w, (int)cpg, GB_ROWS, &b, &r0, &r1);
     if (r1 <= r0) continue;
@@ -641,12 +663,12 @@ __global__ __launch_bounds__(256) void k_graphsum_bwd(A a) {
 // node segments (backward): one wave per (node, part), same split as the forward
 // ------------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(256) void k_seg_bwd(A a) {
-  __shared__ __align__(16) float stage_all[4][STAGE_FLOATS];
+__global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_bwd(A a) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
-  for (int64_t n = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * 4) {
+  for (int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float kv[2][NC + 1], dkv[2][NC + 1];
     seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
@@ -713,8 +735,16 @@ __global__ __launch_bounds__(256) void k_seg_bwd(A a) {
       float* d1 = (P == 2) ? dve + S1 * SLOT : (dvt ? dvt + S1 * SLOT : nullptr);
       float x[8], val[8];
       slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, val);
+      if (P == 2 && te < 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) val[c] = 0.f;
+      }
       kv_bwd_x(L, x, val, dkv[0], d0, ck);
       slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
+      if (P != 2 && te < 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) val[c] = 0.f;
+      }
       kv_bwd_x(L, x, val, dkv[1], d1, ck + SLOT);
       if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
     });
@@ -766,15 +796,15 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
   float* part = cpg > 1 ? (float*)workspace : a->kvg;
-  unsigned g1 = hotk_grid((int64_t)a->B * cpg, 4, 256 * 32);
-  hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(256), 0, st, *a, part, cpg, rows);
+  unsigned g1 = hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP);
+  hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
   if (cpg > 1)
     hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->kvg,
                        a->B, cpg);
-  const dim3 gseg(hotk_grid(a->Nn, 4, 256 * 32));
-  hipLaunchKernelGGL(k_seg_fwd<1>, gseg, dim3(256), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_fwd<2>, gseg, dim3(256), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_fwd<0>, gseg, dim3(256), 0, st, *a);
+  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
+  hipLaunchKernelGGL(k_seg_fwd<1>, gseg, dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_fwd<2>, gseg, dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_fwd<0>, gseg, dim3(TPB), 0, st, *a);
   return hotk_launch_status();
 }
 
@@ -794,14 +824,14 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
   float* part = cpg > 1 ? (float*)workspace : a->dkvg;
-  hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, 4, 256 * 32)), dim3(256), 0, st, *a, part, cpg, rows);
+  hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
   if (cpg > 1)
     hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->dkvg,
                        a->B, cpg);
-  hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->R, 4, 256 * 32)), dim3(256), 0, st, *a);
-  const dim3 gseg(hotk_grid(a->Nn, 4, 256 * 32));
-  hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(256), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(256), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_bwd<0>, gseg, dim3(256), 0, st, *a);
+  hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->R, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
+  hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_seg_bwd<0>, gseg, dim3(TPB), 0, st, *a);
   return hotk_launch_status();
 }
