@@ -50,13 +50,110 @@ def plan_node_graph(plan):
     return plan._node_graph
 
 
+def _plan_counts(plan, n_nodes, n_edges):
+    """Per-node / per-entry element counts of every pool (integer bookkeeping from the CSR pointers, cached on the
+    plan): od/idg = off-diagonal out/in degree per node row, n / Eo per graph, and their gathers to entry rows."""
+    if not hasattr(plan, '_counts'):
+        dev = plan.device
+        f = dict(dtype=torch.float32, device=dev)
+        valid = (plan.nkind == 1)
+        od = ((plan.row_ptr[1:] - plan.row_ptr[:-1] - 1).clamp(min=0) * valid).to(torch.float32).unsqueeze(1)
+        idg = ((plan.col_ptr[1:] - plan.col_ptr[:-1] - 1).clamp(min=0) * valid).to(torch.float32).unsqueeze(1)
+        n_g = torch.as_tensor(n_nodes, **f).unsqueeze(1)                            # [B,1]
+        eo_g = torch.as_tensor(n_edges, **f).unsqueeze(1) - n_g
+        ng = plan_node_graph(plan).long()
+        eg = plan_entry_graph(plan).long()
+        ri, ci = plan.rown.clamp(min=0).long(), plan.coln.clamp(min=0).long()
+        tau = (plan.tpos >= 0).to(torch.float32).unsqueeze(1) * (plan.kind == 2).to(torch.float32).unsqueeze(1)
+        plan._counts = dict(od=od, idg=idg, n_node=n_g[ng], eo_node=eo_g[ng], n_entry=n_g[eg], eo_entry=eo_g[eg],
+                            odi=od[ri], odj=od[ci], idi=idg[ri], idj=idg[ci], tau=tau)
+    return plan._counts
+
+
+def _nrm(x, cnt, normalize):
+    return _safe_div(x, cnt) if normalize else x
+
+
+def _order2_sums(G):
+    """diag [Nn,D], off-diagonal row sums R and column sums C [Nn,D], trace T and off-diagonal total S [B,D]."""
+    plan = G.plan
+    A = G.values.reshape(plan.R, -1)
+    diag = ops.GatherRows.apply(A, plan.diag_pos, plan.diag_node, plan.Nn)
+    R = ops.SegSumRows.apply(A, plan.row_seg(), plan.kind, KEEP_OFFDIAG, plan.rown)
+    C = ops.SegSumRows.apply(A, plan.col_seg(), plan.kind, KEEP_OFFDIAG, plan.coln)
+    eg = plan_entry_graph(plan)
+    T = ops.SegSumRows.apply(A, plan.graph_seg(2), plan.kind, KEEP_DIAG, eg)
+    S = ops.SegSumRows.apply(A, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG, eg)
+    return A, diag, R, C, T, S
+
+
 def basis_1_to_1(G, normalize):
-    raise NotImplementedError("Linear(1,1,cfg='default') is not built yet (light cfg is)")
+    """[x, sum of the other nodes (/ (n-1))]  (linear.py:64-80); the pooled term is left unmasked on padded node
+    rows exactly as in the reference (Linear masks afterwards)."""
+    plan = G.plan
+    x = G.values.reshape(plan.Nn, -1)
+    ng = plan_node_graph(plan)
+    if normalize:
+        n1 = torch.as_tensor(G.n_nodes, dtype=x.dtype, device=x.device)[ng.long()].unsqueeze(1) - 1
+        n1 = torch.where(n1 == 0, torch.full_like(n1, 1e-5), n1)
+        x = x / n1
+        xs = G.values.reshape(plan.Nn, -1)
+    else:
+        xs = x
+    tot = ops.SegSumRows.apply(x, plan.graph_seg(1), plan.nkind, KEEP_DIAG, ng)
+    pooled = ops.GatherSeg.apply(tot, ng, plan.graph_seg(1), plan.Nn) - x
+    return torch.cat([xs, pooled], -1).view(*G.values.shape[:-1], -1)
 
 
 def basis_2_to_1(G, dG, normalize):
-    raise NotImplementedError("Linear(2,1,cfg='default') is not built yet (light cfg is)")
+    """[A_vv, R_v/od, C_v/id, (T - A_vv)/(n-1), (S - R_v - C_v)/(Eo - od - id)]  (linear.py:99-141); the fourth term is
+    not masked on padded node rows, as in the reference."""
+    plan = G.plan
+    c = _plan_counts(plan, G.n_nodes, G.n_edges)
+    A, diag, R, C, T, S = _order2_sums(G)
+    ng = plan_node_graph(plan)
+    nm = (plan.nkind == 1).to(A.dtype).unsqueeze(1)
+    Tn = ops.GatherSeg.apply(T, ng, plan.graph_seg(1), plan.Nn)
+    Sn = ops.GatherSeg.apply(S, ng, plan.graph_seg(1), plan.Nn)
+    V = [diag, _nrm(R, c['od'], normalize) * nm, _nrm(C, c['idg'], normalize) * nm,
+         _nrm(Tn - diag, c['n_node'] - 1, normalize),
+         _nrm(Sn - R - C, c['eo_node'] - c['od'] - c['idg'], normalize) * nm]
+    return torch.cat(V, -1).view(plan.B, plan.Nmax, -1)
 
 
 def basis_2_to_2(G, normalize):
-    raise NotImplementedError("Linear(2,2,cfg='default') is not built yet (light cfg is)")
+    """The 15 order-2 -> order-2 basis tensors (linear.py:143-238) in closed form from the row / column /
+    graph segment sums: O(E) instead of the reference's [B,E,E] masks.  Gathers and segment sums are HIP kernels
+    (hotk_gather_rows / hotk_seg_sum_rows / hotk_mask_rows); the closed-form combination is elementwise."""
+    plan = G.plan
+    c = _plan_counts(plan, G.n_nodes, G.n_edges)
+    A, diag, R, C, T, S = _order2_sums(G)
+    off = lambda X: ops.MaskRows.apply(X, plan.kind, KEEP_OFFDIAG, 0.0)
+    to_d = lambda Xn: ops.GatherRows.apply(Xn, plan.diag_node, plan.diag_pos, plan.R)
+    rows, cols = plan.row_seg(), plan.col_seg()
+    by_i = lambda Xn: ops.GatherSeg.apply(Xn, plan.rown, rows, plan.R)
+    by_j = lambda Xn: ops.GatherSeg.apply(Xn, plan.coln, cols, plan.R)
+    ng, eg = plan_node_graph(plan), plan_entry_graph(plan)
+    nm = (plan.nkind == 1).to(A.dtype).unsqueeze(1)
+    At = ops.GatherRows.apply(A, plan.tpos, plan.tpos, plan.R)
+    Aii, Ajj = by_i(diag), by_j(diag)
+    V = [ops.MaskRows.apply(A, plan.kind, KEEP_DIAG, 0.0), off(A), off(At), off(Aii), off(Ajj)]
+    Tn = ops.GatherSeg.apply(T, ng, plan.graph_seg(1), plan.Nn)
+    Sn = ops.GatherSeg.apply(S, ng, plan.graph_seg(1), plan.Nn)
+    V6 = to_d(_nrm(R, c['od'], normalize) * nm)
+    V7 = to_d(_nrm(C, c['idg'], normalize) * nm)
+    V12 = to_d(_nrm(Tn - diag, c['n_node'] - 1, normalize) * nm)
+    V13 = to_d(_nrm(Sn - R - C, c['eo_node'] - c['od'] - c['idg'], normalize) * nm)
+    Ri, Rj, Ci, Cj = by_i(R), by_j(R), by_i(C), by_j(C)
+    Te = ops.GatherSeg.apply(T, eg, plan.graph_seg(2), plan.R)
+    Se = ops.GatherSeg.apply(S, eg, plan.graph_seg(2), plan.R)
+    tau = c['tau']
+    V8 = off(_nrm(Cj - A, c['idj'] - 1, normalize))
+    V9 = off(_nrm(Ri - A, c['odi'] - 1, normalize))
+    V10 = off(_nrm(Rj - At, c['odj'] - tau, normalize))
+    V11 = off(_nrm(Ci - At, c['idi'] - tau, normalize))
+    V14 = off(_nrm(Te - Aii - Ajj, c['n_entry'] - 2, normalize))
+    V15 = off(_nrm(Se - Ri - Ci - Rj - Cj + A + At,
+                   c['eo_entry'] - c['odi'] - c['idi'] - c['odj'] - c['idj'] + 1 + tau, normalize))
+    V += [V6, V7, V8, V9, V10, V11, V12, V13, V14, V15]
+    return torch.cat(V, -1).view(plan.B, plan.Emax, -1)

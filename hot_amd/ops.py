@@ -155,6 +155,24 @@ class SegSumRows(Function):
         return d.view(ctx.src_shape), None, None, None, None
 
 
+class GatherSeg(Function):
+    """out[r] = src[idx[r]] (zeros where idx < 0) for a many-to-one index: node or graph rows broadcast to the
+    entries / nodes that reference them.  Backward is the matching segment sum (`seg` groups the output rows by
+    source row).  Stands in for torch.gather(diagonal, 1, row_idx / col_idx) and the broadcast halves of the
+    masked bmm poolings (models/sparse/linear.py:157-159,187-231)."""
+
+    @staticmethod
+    def forward(ctx, src, idx, seg, n_out):
+        ctx.seg = seg
+        ctx.src_shape = src.shape
+        return gather_rows(src, idx, n_out)
+
+    @staticmethod
+    def backward(ctx, g):
+        d = seg_sum_rows(g.contiguous(), ctx.seg)
+        return d.view(ctx.src_shape), None, None, None
+
+
 class Phi(Function):
     """Fused FAVOR+ feature map: head split -> projection -> ReLU/exp -> loop + padding masks.
     Stands in for KernelFeatureMapWrapper.forward (models/sparse/kernelattncoef.py:19-28) and

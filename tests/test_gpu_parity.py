@@ -91,13 +91,13 @@ def test_plan_rejects_bad_layout():
 
 
 @pytest.mark.parametrize('name', ['linear_random.npz', 'linear_sym.npz'])
-def test_linear_light_and_pools(name):
+def test_linear_all_bases(name):
     _, _, _, bs, _, ms, _ = _product()
     z = load_golden(name)
     G0 = gpu_batch(z)
     D = G0.values.size(-1)
     cases = [(2, 2, 'light'), (2, 1, 'light'), (1, 1, 'light'), (2, 0, 'light'), (2, 0, 'default'), (1, 0, 'light'),
-             (1, 0, 'default')]
+             (1, 0, 'default'), (2, 2, 'default'), (2, 1, 'default'), (1, 1, 'default')]
     for (oi, oo, cfg) in cases:
         for nrm in (1, 0):
             tag = f'l{oi}{oo}_{cfg}_{nrm}'
