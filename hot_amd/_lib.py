@@ -32,6 +32,9 @@ _SIGNATURES = {
     'hotk_bias_grad_rows': [_P, _L, _P, _P, _P, _L, _L, _P],
     'hotk_basis22_light_fwd': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_basis22_light_bwd': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
+    'hotk_basis22_pair_fwd': [_P, _L, _P, _P, _P, _L, _L, _L, _P],
+    'hotk_basis22_pair_bwd': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _L, _L, _P],
+    'hotk_assemble22': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_phi_fwd': [_P, _L, _P, _P, _U, _P, _L, _L, _I, _I, _I, _I, _P, _P],
     'hotk_phi_bwd': [_P, _L, _P, _P, _U, _P, _L, _P, _L, _L, _I, _I, _I, _I, _P, _P],
     'hotk_phi_stats_workspace_bytes': [_L, _I, _I, ctypes.POINTER(_S)],

@@ -222,6 +222,80 @@ __global__ void k_basis22_light_bwd(const float* __restrict__ g, int64_t ld_g, c
   }
 }
 
+// ------------------------------------------------------------------ order-2 'light' basis, factored form
+// The five-block basis [diag? x | off? x | off&tau? x_t | off? x_(i,i) | off? x_(j,j)] @ W is linear in its blocks, so
+// the three node-valued blocks are projected once per NODE ([Nn,D] @ [W1|W4|W5]) and only the two entry-valued
+// blocks go through the big GEMM:  x2[r] = off-diagonal ? [ x_r | tau ? x_t(r) : 0 ] : 0   ([R, 2D]).
+template <int V>
+__global__ void k_basis22_pair_fwd(const float* __restrict__ x, int64_t ld_x, const uint8_t* __restrict__ kind,
+                                   const int32_t* __restrict__ tpos, float* __restrict__ x2, int64_t ld_x2, int64_t R,
+                                   int64_t D) {
+  using T = typename VecT<V>::type;
+  const int64_t DV = D / V, total = R * DV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / DV, c = (t - r * DV) * V;
+    T a = vzero(T()), b = a;
+    if (kind[r] == 2) {
+      a = *reinterpret_cast<const T*>(x + r * ld_x + c);
+      int32_t tp = tpos[r];
+      if (tp >= 0) b = *reinterpret_cast<const T*>(x + (int64_t)tp * ld_x + c);
+    }
+    float* o = x2 + r * ld_x2 + c;
+    *reinterpret_cast<T*>(o) = a;
+    *reinterpret_cast<T*>(o + D) = b;
+  }
+}
+
+// transpose map of k_basis22_pair_fwd plus the node-level gradient on the diagonal rows
+template <int V>
+__global__ void k_basis22_pair_bwd(const float* __restrict__ g, int64_t ld_g, const uint8_t* __restrict__ kind,
+                                   const int32_t* __restrict__ tpos, const int32_t* __restrict__ rown,
+                                   const float* __restrict__ gd, int64_t ld_gd, float* __restrict__ dx, int64_t ld_dx,
+                                   int64_t R, int64_t D) {
+  using T = typename VecT<V>::type;
+  const int64_t DV = D / V, total = R * DV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / DV, c = (t - r * DV) * V;
+    uint8_t kd = kind[r];
+    T acc = vzero(T());
+    if (kd == 2) {
+      acc = *reinterpret_cast<const T*>(g + r * ld_g + c);
+      int32_t tp = tpos[r];  // x_r is the transposed input of row tp
+      if (tp >= 0) acc = vadd(acc, *reinterpret_cast<const T*>(g + (int64_t)tp * ld_g + D + c));
+    } else if (kd == 1) {
+      acc = *reinterpret_cast<const T*>(gd + (int64_t)rown[r] * ld_gd + c);
+    }
+    *reinterpret_cast<T*>(dx + r * ld_dx + c) = acc;
+  }
+}
+
+// y[r] (in place on the big GEMM's output z):  off-diagonal (i,j): z + yn[i][C..2C) + yn[j][2C..3C) + b_off
+//                                               diagonal (v,v)   : yn[v][0..C) + b_diag          padding: 0
+template <int V>
+__global__ void k_assemble22(float* __restrict__ z, int64_t ld, const float* __restrict__ yn, int64_t ld_yn,
+                             const uint8_t* __restrict__ kind, const int32_t* __restrict__ rown,
+                             const int32_t* __restrict__ coln, const float* __restrict__ b_off,
+                             const float* __restrict__ b_diag, int64_t R, int64_t C) {
+  using T = typename VecT<V>::type;
+  const int64_t CV = C / V, total = R * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t r = t / CV, c = (t - r * CV) * V;
+    uint8_t kd = kind[r];
+    T* p = reinterpret_cast<T*>(z + r * ld + c);
+    T v = vzero(T());
+    if (kd == 2) {
+      v = *p;
+      v = vadd(v, *reinterpret_cast<const T*>(yn + (int64_t)rown[r] * ld_yn + C + c));
+      v = vadd(v, *reinterpret_cast<const T*>(yn + (int64_t)coln[r] * ld_yn + 2 * C + c));
+      if (b_off) v = vadd(v, *reinterpret_cast<const T*>(b_off + c));
+    } else if (kd == 1) {
+      v = *reinterpret_cast<const T*>(yn + (int64_t)rown[r] * ld_yn + c);
+      if (b_diag) v = vadd(v, *reinterpret_cast<const T*>(b_diag + c));
+    }
+    *p = v;
+  }
+}
+
 inline bool vec4_ok(int64_t C, std::initializer_list<int64_t> lds, std::initializer_list<const void*> ptrs) {
   if (C % 4) return false;
   for (int64_t l : lds) if (l % 4) return false;
@@ -365,6 +439,56 @@ extern "C" int hotk_basis22_light_bwd(const float* dx5, int64_t ld_dx5, const ui
   } else {
     hipLaunchKernelGGL(k_basis22_light_bwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, dx5, ld_dx5, kind, rown,
                        tpos, row_ptr, row_perm, col_ptr, col_perm, dx, ld_dx, R, D);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_basis22_pair_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
+                                     int64_t ld_x2, int64_t R, int64_t D, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_x >= D && ld_x2 >= 2 * D);
+  if (R == 0 || D == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(x && kind && tpos && x2);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(D, {ld_x, ld_x2}, {x, x2})) {
+    hipLaunchKernelGGL(k_basis22_pair_fwd<4>, dim3(hotk_grid(R * (D / 4), 256)), dim3(256), 0, st, x, ld_x, kind, tpos, x2,
+                       ld_x2, R, D);
+  } else {
+    hipLaunchKernelGGL(k_basis22_pair_fwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, x, ld_x, kind, tpos, x2,
+                       ld_x2, R, D);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind, const int32_t* tpos,
+                                     const int32_t* rown, const float* dxd, int64_t ld_dxd, float* dx, int64_t ld_dx,
+                                     int64_t R, int64_t D, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_dx >= D && ld_dx2 >= 2 * D && ld_dxd >= D);
+  if (R == 0 || D == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(dx2 && kind && tpos && rown && dxd && dx);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(D, {ld_dx2, ld_dxd, ld_dx}, {dx2, dxd, dx})) {
+    hipLaunchKernelGGL(k_basis22_pair_bwd<4>, dim3(hotk_grid(R * (D / 4), 256)), dim3(256), 0, st, dx2, ld_dx2, kind, tpos,
+                       rown, dxd, ld_dxd, dx, ld_dx, R, D);
+  } else {
+    hipLaunchKernelGGL(k_basis22_pair_bwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, dx2, ld_dx2, kind, tpos, rown,
+                       dxd, ld_dxd, dx, ld_dx, R, D);
+  }
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_assemble22(float* z, int64_t ld, const float* yn, int64_t ld_yn, const uint8_t* kind,
+                               const int32_t* rown, const int32_t* coln, const float* b_off, const float* b_diag,
+                               int64_t R, int64_t C, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && C >= 0 && ld >= C && ld_yn >= 3 * C);
+  if (R == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(z && yn && kind && rown && coln);
+  hipStream_t st = (hipStream_t)stream;
+  if (vec4_ok(C, {ld, ld_yn}, {z, yn, b_off, b_diag})) {
+    hipLaunchKernelGGL(k_assemble22<4>, dim3(hotk_grid(R * (C / 4), 256)), dim3(256), 0, st, z, ld, yn, ld_yn, kind, rown,
+                       coln, b_off, b_diag, R, C);
+  } else {
+    hipLaunchKernelGGL(k_assemble22<1>, dim3(hotk_grid(R * C, 256)), dim3(256), 0, st, z, ld, yn, ld_yn, kind, rown, coln,
+                       b_off, b_diag, R, C);
   }
   return hotk_launch_status();
 }

@@ -77,12 +77,19 @@ class Linear(nn.Module):
         self.weight = _Weight(ord_in, ord_out, in_dim, out_dim, cfg, normalize)
         if bias:
             self.bias = _Bias(ord_out, out_dim)
+        self.factored = True   # 2->2 'light': node-level blocks projected per node (ops.Linear22Light)
 
     def forward(self, G: Union[B, torch.Tensor]) -> Union[B, torch.Tensor]:
         """A' = L A with L a learned combination of the equivariant basis; returns Batch (order 1/2) or
         Tensor [B, D'] (order 0)."""
-        H, y = self.weight(G)
         bias = self.bias.bias if hasattr(self, 'bias') else None
+        w = self.weight
+        if self.factored and (w.ord_in, w.ord_out, w.cfg) == (2, 2, 'light'):
+            assert isinstance(G, B) and G.order == 2
+            y = ops.Linear22Light.apply(G.values, w.weight, None if bias is None else bias[0],
+                                        None if bias is None else bias[1], G.plan)
+            return batch_like(G, y, skip_masking=True)
+        H, y = self.weight(G)
         if H is None:
             return y if bias is None else y + bias[0][None, :]
         plan = H.plan
