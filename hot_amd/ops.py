@@ -278,10 +278,6 @@ class Linear22Light(Function):
         g = g.contiguous().view(plan.R, C)
         if plan.Ev != plan.R:
             g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)      # padding rows of an upstream gradient may hold anything
-        db_off = torch.zeros(C, dtype=g.dtype, device=dev) if ctx.has_b[0] else None
-        db_diag = torch.zeros(C, dtype=g.dtype, device=dev) if ctx.has_b[1] else None
-        if db_off is not None or db_diag is not None:
-            call('hotk_bias_grad_rows', 4 * plan.R * C, p(g), C, p(plan.kind), p(db_off), p(db_diag), plan.R, C)
         # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
         long_seg = max(plan.max_row_deg, plan.max_col_deg) > SEG_CHUNK
         dyn = (torch.zeros if long_seg else torch.empty)(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
@@ -289,6 +285,10 @@ class Linear22Light(Function):
         for k, (beg, end, perm, maxlen) in ((1, plan.row_seg()), (2, plan.col_seg())):
             call('hotk_seg_sum_rows', 4 * C * (plan.Ev + plan.Nn), p(g), C, p(beg), p(end), p(perm), p(plan.kind),
                  KEEP_OFFDIAG, c_void_p_of(dyn, k * C), 3 * C, plan.Nn, C, maxlen)
+        # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
+        # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows
+        db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
+        db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
         Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
         dx = dW = None
         if ctx.needs_input_grad[0]:
@@ -429,8 +429,16 @@ class RowsMatmul(Function):
         g2 = g.reshape(-1, g.size(-1))
         x2 = x.reshape(-1, x.size(-1))
         dx = (g2 @ w.t()).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = wgrad(x2, g2) if ctx.needs_input_grad[1] else None
-        db = g2.sum(0) if ctx.has_b and ctx.needs_input_grad[2] else None
+        dw = db = None
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[1] and want_b and g2.size(1) > 2 * x2.size(1) and x2.size(0) >= (1 << 16):
+            # g is the wide operand: [x | 1]^T @ g yields dW and db in ONE pass over g
+            xa = torch.cat([x2, torch.ones(x2.size(0), 1, dtype=x2.dtype, device=x2.device)], dim=1)
+            dwa = wgrad(xa, g2)
+            dw, db = dwa[:-1], dwa[-1]
+        else:
+            dw = wgrad(x2, g2) if ctx.needs_input_grad[1] else None
+            db = g2.sum(0) if want_b else None
         return dx, dw, db
 
 
