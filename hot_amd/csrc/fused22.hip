@@ -4,69 +4,47 @@
 // models/sparse/kernelattncoef.py:74-234 ten times; here the ten terms are produced by
 //
 //   graph sums   : one wave per row chunk keeps the four per-graph  sum phi(K) (x) [V|1]  in registers
-//   node segments: one wave per node j keeps the six per-node       sum_i phi(K_i) (x) [V_ij|1]  (36+18 floats
-//                  per lane) in registers while it walks column segment j, and immediately applies them to the
-//                  node's own query, to the entries of column j and to the entries of row j.  No key-value
-//                  tensor, no phi(Q)/phi(K) tensor and no transposed value copy ever reaches HBM.
+//   node segments: one wave per (node j, part) keeps two per-node   sum_i phi(K_i) (x) [V_ij|1]  (2 x 9 floats per
+//                  lane) in registers while it walks column segment j, and immediately applies them to the node's
+//                  own query, to the entries of column j or to the entries of row j.  No key-value tensor, no
+//                  phi(Q)/phi(K) tensor and no transposed value copy ever reaches HBM.
 //
-// Lane l = (head h = l>>4, feature mm = l&15).  A lane computes phi for its (h,mm) from the raw 8-wide head
-// slice (wave-broadcast 16-B loads), products with the 8-wide value / gradient slice of head h, and the
-// 16-lane sums with xor-shuffles that stay inside the head (shuffle-transpose reduction: 8 results in 8 steps).
+// The kernels are VALU-bound (measured: HBM traffic within 1.2x of the algorithmic bytes at ~2 TB/s), so the
+// arithmetic is laid out to need as few vector instructions as possible.  Two lane layouts of a 16-lane DPP row
+// (= one head h = lane >> 4, x = lane & 15):
+//   F layout: lane (h, x) owns random feature mm = x: phi, the 9 key-value accumulators KV[h][mm][0..8];
+//             accumulation  KV[mm][c] += phi[mm] * v[c]  needs no cross-lane traffic at all.
+//   C layout: lane (h, x) owns output channel c = x (0..7 values, 8..15 the normaliser) and holds the ROTATED
+//             column  rot[k] = KV[h][(x - k) & 15][c];  a contraction over the 16 features is then
+//             sum_k row_ror_k(phi) * rot[k]  = 16 DPP multiply-adds, with no reduction tree, select or LDS traffic.
+// The same rotated form of the projection matrix turns  d(raw q)[j] = sum_mm dpre[mm] P[mm][j]  into 16 DPP FMAs.
 #include "common.h"
 
 namespace {
 
 constexpr int NH = 4, NM = 16, DH = 8, NC = 8;  // heads, features, head width, value width per head
 constexpr int SLOT = 32;                        // floats per dim_qk / dim_v slot (NH*DH == NH*NC == 32)
+constexpr int KVG_C = 25;                       // per-graph sums in memory: [B][4][25][64] = 9 F-layout + 16 rotated
 constexpr float PHI_EPS = 1e-3f;
 
 using A = hotk_attn22_args;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 
-struct Lane {
-  int lane, h, mm;
-  float ps[DH];  // P[mm][:] * d^-1/4
-};
-
-__device__ __forceinline__ Lane make_lane(const float* __restrict__ proj) {
-  Lane L;
-  L.lane = threadIdx.x & 63;
-  L.h = L.lane >> 4;
-  L.mm = L.lane & 15;
-  const float scale = 0.59460355750136051f;  // 8^-1/4
-#pragma unroll
-  for (int j = 0; j < DH; ++j) L.ps[j] = proj[L.mm * DH + j] * scale;
-  return L;
-}
-
-// pre-activation of feature (h,mm) for the raw 32-wide slot at x
-__device__ __forceinline__ float pre_of(const Lane& L, const float* __restrict__ x) {
-  float4 a = ld4(x + L.h * DH), b = ld4(x + L.h * DH + 4);
-  float s = a.x * L.ps[0];
-  s = fmaf(a.y, L.ps[1], s); s = fmaf(a.z, L.ps[2], s); s = fmaf(a.w, L.ps[3], s);
-  s = fmaf(b.x, L.ps[4], s); s = fmaf(b.y, L.ps[5], s); s = fmaf(b.z, L.ps[6], s); s = fmaf(b.w, L.ps[7], s);
-  return s;
-}
-__device__ __forceinline__ float phi_of(float pre) { return fmaxf(pre, 0.f) + PHI_EPS; }
-
-// load the 8-wide slice of head h of a 32-wide slot (zeros if p == nullptr)
-__device__ __forceinline__ void ld8(const Lane& L, const float* __restrict__ p, float (&o)[NC]) {
-  if (p) {
-    float4 a = ld4(p + L.h * NC), b = ld4(p + L.h * NC + 4);
-    o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
-  } else {
-#pragma unroll
-    for (int c = 0; c < NC; ++c) o[c] = 0.f;
-  }
-}
-
-// ---- 16-lane (one DPP row = one head) reductions on the VALU: no LDS round trips ---------------------------
-// DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141
+// ---- 16-lane (one DPP row = one head) data movement on the VALU ---------------------------------------------
+// DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141,
+// row_ror:k = 0x120 + k (lane x reads lane (x - k) & 15 of its row)
 template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
+template <int K>
+__device__ __forceinline__ float ror(float v) { return dpp<0x120 + K>(v); }
+// source lane of row_ror:k
+#ifndef HOTK_ROR_DIR
+#define HOTK_ROR_DIR (-1)
+#endif
+__device__ __host__ __forceinline__ int ror_src(int x, int k) { return (x + HOTK_ROR_DIR * k) & 15; }
 
 // sum over the 16 lanes of a head, result in every lane
 __device__ __forceinline__ float head_allsum(float v) {
@@ -77,114 +55,77 @@ __device__ __forceinline__ float head_allsum(float v) {
   return v;
 }
 
-// element index held by lane mm after head_sum8, and whether this lane is the one that stores it
-__device__ __forceinline__ int sum8_idx(int mm) { return 4 * (mm >> 3) + 2 * ((mm >> 2) & 1) + (mm & 1); }
-__device__ __forceinline__ bool sum8_owner(int mm) { return (mm & 2) == 0; }
-
-// t[0..7] per lane -> sum over the head's 16 lanes of t[sum8_idx(mm)] (shuffle-transpose reduction: each step
-// halves the number of live values while adding the mirrored partner's half)
-__device__ __forceinline__ float head_sum8(const Lane& L, const float (&t)[8]) {
-  const bool hi8 = L.mm & 8, hi4 = L.mm & 4, odd = L.mm & 1;
-  float w[4], u[2];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const float give = hi8 ? t[k] : t[k + 4];
-    const float keep = hi8 ? t[k + 4] : t[k];
-    w[k] = keep + dpp<0x140>(give);          // partner 15 - mm
+// acc += row_ror_K(v) * r as ONE instruction.  hipcc (ROCm 7.2) folds a DPP move into v_mul_f32 but not into
+// v_fmac_f32, so the multiply-add form is written out; the asm statements are volatile (kept in program order) and
+// the first one of a contraction carries the two wait states a DPP read needs after the VALU write of its source.
+template <int K>
+__device__ __forceinline__ void fmac_ror(float& acc, float v, float r);
+#define HOTK_FMAC_ROR(K)                                                                                         \
+  template <>                                                                                                    \
+  __device__ __forceinline__ void fmac_ror<K>(float& acc, float v, float r) {                                    \
+    asm volatile("v_fmac_f32_dpp %0, %1, %2 row_ror:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1"             \
+                 : "+v"(acc) : "v"(v), "v"(r));                                                                  \
   }
-#pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const float give = hi4 ? w[k] : w[k + 2];
-    const float keep = hi4 ? w[k + 2] : w[k];
-    u[k] = keep + dpp<0x141>(give);          // partner 7 - (mm & 7) within the half
-  }
-  const float give = odd ? u[0] : u[1];
-  const float keep = odd ? u[1] : u[0];
-  float r = keep + dpp<0xB1>(give);          // partner mm ^ 1
-  r += dpp<0x4E>(r);                         // partner mm ^ 2
-  return r;
+HOTK_FMAC_ROR(2) HOTK_FMAC_ROR(3) HOTK_FMAC_ROR(4) HOTK_FMAC_ROR(5) HOTK_FMAC_ROR(6) HOTK_FMAC_ROR(7) HOTK_FMAC_ROR(8)
+HOTK_FMAC_ROR(9) HOTK_FMAC_ROR(10) HOTK_FMAC_ROR(11) HOTK_FMAC_ROR(12) HOTK_FMAC_ROR(13) HOTK_FMAC_ROR(14) HOTK_FMAC_ROR(15)
+#undef HOTK_FMAC_ROR
+
+// sum_k v[(x - k) & 15] * rot[k]: the 16-feature contraction of the C layout (two accumulation chains)
+__device__ __forceinline__ float rot_dot(float v, const float (&rot)[NM]) {
+  float a0 = v * rot[0];
+  float a1;
+  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+               : "=v"(a1) : "v"(v), "v"(rot[1]));
+  fmac_ror<2>(a0, v, rot[2]);
+  fmac_ror<3>(a1, v, rot[3]);
+  fmac_ror<4>(a0, v, rot[4]);
+  fmac_ror<5>(a1, v, rot[5]);
+  fmac_ror<6>(a0, v, rot[6]);
+  fmac_ror<7>(a1, v, rot[7]);
+  fmac_ror<8>(a0, v, rot[8]);
+  fmac_ror<9>(a1, v, rot[9]);
+  fmac_ror<10>(a0, v, rot[10]);
+  fmac_ror<11>(a1, v, rot[11]);
+  fmac_ror<12>(a0, v, rot[12]);
+  fmac_ror<13>(a1, v, rot[13]);
+  fmac_ror<14>(a0, v, rot[14]);
+  fmac_ror<15>(a1, v, rot[15]);
+  return a0 + a1;
 }
 
-// store the head_sum8 result: slot base p (32 floats), element h*8 + sum8_idx(mm)
-__device__ __forceinline__ void st_sum8(const Lane& L, float* __restrict__ p, float r) {
-  if (sum8_owner(L.mm)) p[L.h * 8 + sum8_idx(L.mm)] = r;
+struct Lane {
+  int lane, h, x;
+  float ps[DH];  // F layout: P[x][:] * d^-1/4
+};
+struct LaneB : Lane {
+  float pr[NM];  // rotated projection: P[(x - k) & 15][x & 7] * d^-1/4   (backward kernels only)
+};
+
+constexpr float PSCALE = 0.59460355750136051f;  // 8^-1/4
+
+__device__ __forceinline__ void init_lane(Lane& L, const float* __restrict__ proj) {
+  L.lane = threadIdx.x & 63;
+  L.h = L.lane >> 4;
+  L.x = L.lane & 15;
+#pragma unroll
+  for (int j = 0; j < DH; ++j) L.ps[j] = proj[L.x * DH + j] * PSCALE;
+}
+__device__ __forceinline__ Lane make_lane(const float* __restrict__ proj) {
+  Lane L;
+  init_lane(L, proj);
+  return L;
+}
+__device__ __forceinline__ LaneB make_lane_b(const float* __restrict__ proj) {
+  LaneB L;
+  init_lane(L, proj);
+#pragma unroll
+  for (int k = 0; k < NM; ++k) L.pr[k] = proj[ror_src(L.x, k) * DH + (L.x & 7)] * PSCALE;
+  return L;
 }
 
-__device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
-  for (int i = L.lane; i < nslots * SLOT; i += 64) p[i] = 0.f;
-}
+__device__ __forceinline__ float phi_of(float pre) { return fmaxf(pre, 0.f) + PHI_EPS; }
 
-// KV accumulate: kv[0..7] += phi * val, kv[8] += phi
-__device__ __forceinline__ void kv_acc(float (&kv)[NC + 1], float phi, const float (&val)[NC]) {
-#pragma unroll
-  for (int c = 0; c < NC; ++c) kv[c] = fmaf(phi, val[c], kv[c]);
-  kv[NC] += phi;
-}
-
-// O = phi(q).KV / guard(phi(q).ks) for one slot; writes 32 floats at out
-__device__ __forceinline__ void apply_fwd(const Lane& L, const float* __restrict__ q, const float (&kv)[NC + 1],
-                                          float* __restrict__ out) {
-  const float phi = phi_of(pre_of(L, q));
-  float t[8];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) t[c] = phi * kv[c];
-  float den = head_allsum(phi * kv[NC]);
-  if (den == 0.f) den = 1e-5f;
-  float r = head_sum8(L, t);
-  st_sum8(L, out, r / den);
-}
-
-// backward of apply_fwd: writes d(raw q) (32 floats at dq) and accumulates dkv
-__device__ __forceinline__ void apply_bwd(const Lane& L, const float* __restrict__ q, const float (&kv)[NC + 1],
-                                          const float* __restrict__ dO, float* __restrict__ dq,
-                                          float (&dkv)[NC + 1]) {
-  const float pre = pre_of(L, q);
-  const float phi = phi_of(pre);
-  float g[NC];
-  ld8(L, dO, g);
-  float s = 0.f;
-#pragma unroll
-  for (int c = 0; c < NC; ++c) s = fmaf(kv[c], g[c], s);
-  float den = head_allsum(phi * kv[NC]);
-  const float dot = head_allsum(phi * s);
-  const bool guarded = (den == 0.f);
-  if (guarded) den = 1e-5f;
-  const float inv = __builtin_amdgcn_rcpf(den);
-  const float dden = guarded ? 0.f : -dot * inv * inv;
-  const float dphi = fmaf(kv[NC], dden, s * inv);
-#pragma unroll
-  for (int c = 0; c < NC; ++c) dkv[c] = fmaf(phi, g[c] * inv, dkv[c]);
-  dkv[NC] = fmaf(phi, dden, dkv[NC]);
-  const float dpre = pre > 0.f ? dphi : 0.f;
-  float t[8];
-#pragma unroll
-  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
-  st_sum8(L, dq, head_sum8(L, t));
-}
-
-// backward of one KV accumulation term: dV (32 floats at dv, may be null) and d(raw key) (32 floats at dk)
-__device__ __forceinline__ void kv_bwd(const Lane& L, const float* __restrict__ k, const float* __restrict__ val_p,
-                                       const float (&dkv)[NC + 1], float* __restrict__ dv, float* __restrict__ dk) {
-  const float pre = pre_of(L, k);
-  const float phi = phi_of(pre);
-  float val[NC];
-  ld8(L, val_p, val);
-  float t[8];
-  float dphi = dkv[NC];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    t[c] = phi * dkv[c];
-    dphi = fmaf(dkv[c], val[c], dphi);
-  }
-  float r = head_sum8(L, t);
-  if (dv) st_sum8(L, dv, r);
-  const float dpre = pre > 0.f ? dphi : 0.f;
-#pragma unroll
-  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
-  st_sum8(L, dk, head_sum8(L, t));
-}
-
-// ---- register-slice forms: the 8-wide head slices come out of the wave's LDS staging row --------------------
+// pre-activation of feature (h, x) from the 8-wide head slice
 __device__ __forceinline__ float pre_x(const Lane& L, const float (&x)[DH]) {
   float s = x[0] * L.ps[0];
 #pragma unroll
@@ -192,42 +133,89 @@ __device__ __forceinline__ float pre_x(const Lane& L, const float (&x)[DH]) {
   return s;
 }
 
+// the 8-float slice of head h of a 32-float slot staged in the wave's LDS row
 __device__ __forceinline__ void slice8(const Lane& L, const float* lds_slot, float (&o)[8]) {
   const float4 a = *reinterpret_cast<const float4*>(lds_slot + L.h * 8);
   const float4 b = *reinterpret_cast<const float4*>(lds_slot + L.h * 8 + 4);
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
 }
 
+// The staging rows are private to the wave and the LDS executes one wave's instructions in order, so only the
+// COMPILER has to be kept from moving the cross-lane reads over the writes: wavefront-scope fences.
+__device__ __forceinline__ void wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int NR>
 __device__ __forceinline__ void stage_put(const Lane& L, float* stage, const float (&r)[NR]) {
-  // The staging row is private to the wave and the LDS executes one wave's instructions in order, so only the
-  // COMPILER has to be kept from moving the cross-lane reads over the writes: wavefront-scope fences.
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  wave_fence();
 #pragma unroll
   for (int t = 0; t < NR; ++t) stage[t * 64 + L.lane] = r[t];
-  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  wave_fence();
 }
 
-__device__ __forceinline__ void apply_fwd_x(const Lane& L, const float (&q)[DH], const float (&kv)[NC + 1],
-                                            float* __restrict__ out) {
-  const float phi = phi_of(pre_x(L, q));
-  float t[8];
+// KV accumulate (F layout): kv[0..7] += phi * val, kv[8] += phi
+__device__ __forceinline__ void kv_acc(float (&kv)[NC + 1], float phi, const float (&val)[NC]) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) t[c] = phi * kv[c];
-  float den = head_allsum(phi * kv[NC]);
-  if (den == 0.f) den = 1e-5f;
-  st_sum8(L, out, head_sum8(L, t) * __builtin_amdgcn_rcpf(den));
+  for (int c = 0; c < NC; ++c) kv[c] = fmaf(phi, val[c], kv[c]);
+  kv[NC] += phi;
+}
+// the same with the value channels scaled by s (0 when the transposed entry is absent): the normaliser channel
+// still counts the key (kernelattncoef.py:103-122 sums keys over every entry of the column)
+__device__ __forceinline__ void kv_acc_scaled(float (&kv)[NC + 1], float phi, const float (&val)[NC], float s) {
+  const float ps = phi * s;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) kv[c] = fmaf(ps, val[c], kv[c]);
+  kv[NC] += phi;
 }
 
-__device__ __forceinline__ void apply_bwd_x(const Lane& L, const float (&q)[DH], const float (&kv)[NC + 1],
-                                            const float (&g)[NC], float* __restrict__ dq, float (&dkv)[NC + 1]) {
+// F layout -> C layout through the wave's LDS scratch (4 heads x 32 rows x 9 floats): every feature row is written
+// twice, 16 rows apart, so that row (x - k) & 15 is the plain row x + 16 - k and all 16 reads use immediate offsets.
+// DUP: lanes 8..15 repeat channels 0..7 (gradient of the values) instead of holding the normaliser channel.
+constexpr int KVBUF_FLOATS = NH * 32 * (NC + 1);
+template <bool DUP>
+__device__ __forceinline__ void kv_to_rot(const Lane& L, float* kvbuf, const float (&kv)[NC + 1], float (&rot)[NM]) {
+  wave_fence();
+  float* w = kvbuf + (L.h * 32 + L.x) * (NC + 1);
+#pragma unroll
+  for (int c = 0; c <= NC; ++c) {
+    w[c] = kv[c];
+    w[16 * (NC + 1) + c] = kv[c];
+  }
+  wave_fence();
+  const int cidx = DUP ? (L.x & 7) : (L.x < NC ? L.x : NC);
+  if (HOTK_ROR_DIR < 0) {
+    const float* r = kvbuf + (L.h * 32 + L.x + 1) * (NC + 1) + cidx;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) rot[k] = r[(15 - k) * (NC + 1)];
+  } else {
+    const float* r = kvbuf + (L.h * 32 + L.x) * (NC + 1) + cidx;
+#pragma unroll
+    for (int k = 0; k < NM; ++k) rot[k] = r[k * (NC + 1)];
+  }
+}
+
+// O = phi(q).KV / guard(phi(q).ks) for one slot (C layout: lanes x < 8 hold the 8 outputs of head h, lanes x >= 8 the
+// normaliser); writes 32 floats at out
+__device__ __forceinline__ void apply_fwd(const Lane& L, const float (&q)[DH], const float (&rot)[NM],
+                                          float* __restrict__ out) {
+  const float phi = phi_of(pre_x(L, q));
+  const float num = rot_dot(phi, rot);
+  float den = ror<8>(num);
+  if (den == 0.f) den = 1e-5f;
+  const float o = num * __builtin_amdgcn_rcpf(den);
+  if (L.x < NC) out[L.h * NC + L.x] = o;
+}
+
+// backward of apply_fwd: writes d(raw q) (32 floats at dq) and accumulates dkv (F layout)
+__device__ __forceinline__ void apply_bwd(const LaneB& L, const float (&q)[DH], const float (&kv)[NC + 1],
+                                          const float (&g)[NC], float* __restrict__ dq, float (&dkv)[NC + 1]) {
   const float pre = pre_x(L, q);
   const float phi = phi_of(pre);
-  float s = 0.f;
+  float s = kv[0] * g[0];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) s = fmaf(kv[c], g[c], s);
+  for (int c = 1; c < NC; ++c) s = fmaf(kv[c], g[c], s);
   float den = head_allsum(phi * kv[NC]);
   const float dot = head_allsum(phi * s);
   const bool guarded = (den == 0.f);
@@ -235,33 +223,34 @@ __device__ __forceinline__ void apply_bwd_x(const Lane& L, const float (&q)[DH],
   const float inv = __builtin_amdgcn_rcpf(den);
   const float dden = guarded ? 0.f : -dot * inv * inv;
   const float dphi = fmaf(kv[NC], dden, s * inv);
+  const float pi = phi * inv;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) dkv[c] = fmaf(phi, g[c] * inv, dkv[c]);
+  for (int c = 0; c < NC; ++c) dkv[c] = fmaf(pi, g[c], dkv[c]);
   dkv[NC] = fmaf(phi, dden, dkv[NC]);
   const float dpre = pre > 0.f ? dphi : 0.f;
-  float t[8];
-#pragma unroll
-  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
-  st_sum8(L, dq, head_sum8(L, t));
+  const float d = rot_dot(dpre, L.pr);
+  if (L.x < DH) dq[L.h * DH + L.x] = d;
 }
 
-__device__ __forceinline__ void kv_bwd_x(const Lane& L, const float (&k)[DH], const float (&val)[NC],
-                                         const float (&dkv)[NC + 1], float* __restrict__ dv, float* __restrict__ dk) {
+// backward of one KV accumulation term: dV (32 floats at dv, may be null; drot = C layout of dKV with DUP) and
+// d(raw key) (32 floats at dk)
+__device__ __forceinline__ void kv_bwd(const LaneB& L, const float (&k)[DH], const float (&val)[NC],
+                                       const float (&dkv)[NC + 1], const float (&drot)[NM], float* __restrict__ dv,
+                                       float* __restrict__ dk) {
   const float pre = pre_x(L, k);
   const float phi = phi_of(pre);
-  float t[8];
   float dphi = dkv[NC];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    t[c] = phi * dkv[c];
-    dphi = fmaf(dkv[c], val[c], dphi);
-  }
-  const float r = head_sum8(L, t);
-  if (dv) st_sum8(L, dv, r);
+  for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
+  const float dvv = rot_dot(phi, drot);
+  if (dv && L.x < NC) dv[L.h * NC + L.x] = dvv;
   const float dpre = pre > 0.f ? dphi : 0.f;
-#pragma unroll
-  for (int j = 0; j < DH; ++j) t[j] = dpre * L.ps[j];
-  st_sum8(L, dk, head_sum8(L, t));
+  const float d = rot_dot(dpre, L.pr);
+  if (L.x < DH) dk[L.h * DH + L.x] = d;
+}
+
+__device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
+  for (int i = L.lane; i < nslots * SLOT; i += 64) p[i] = 0.f;
 }
 
 // Software pipeline over `cnt` items, DEPTH 4: the NR coalesced row loads of items k+1..k+3 are in flight while
@@ -289,12 +278,20 @@ __device__ __forceinline__ void pipeline4(int cnt, LoadF load, UseF use) {
 
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
-// per-graph KV registers <-> memory, layout [B][4][9][64]
-__device__ __forceinline__ void kvg_load(const Lane& L, const float* __restrict__ base, float (&kv)[NC + 1]) {
-#pragma unroll
-  for (int c = 0; c <= NC; ++c) kv[c] = base[c * 64 + L.lane];
+// per-graph sums <-> memory: slot base = [KVG_C][64] floats, channels 0..8 F layout, 9..24 rotated
+__device__ __forceinline__ const float* kvg_slot(const float* base, int64_t b, int s) {
+  return base + ((b * 4 + s) * KVG_C) * 64;
 }
-__device__ __forceinline__ void kvg_store(const Lane& L, float* __restrict__ base, const float (&kv)[NC + 1]) {
+__device__ __forceinline__ void kvg_load(const Lane& L, const float* __restrict__ slot, float (&kv)[NC + 1]) {
+#pragma unroll
+  for (int c = 0; c <= NC; ++c) kv[c] = slot[c * 64 + L.lane];
+}
+__device__ __forceinline__ void kvg_load_rot(const Lane& L, const float* __restrict__ slot, float (&rot)[NM]) {
+#pragma unroll
+  for (int k = 0; k < NM; ++k) rot[k] = slot[(NC + 1 + k) * 64 + L.lane];
+}
+// partial sums of one chunk: [4][9][64]
+__device__ __forceinline__ void part_store(const Lane& L, float* __restrict__ base, const float (&kv)[NC + 1]) {
 #pragma unroll
   for (int c = 0; c <= NC; ++c) base[c * 64 + L.lane] = kv[c];
 }
@@ -316,9 +313,6 @@ constexpr int TPB = 64 * WPB;
 #define HOTK_GRID_CAP (1 << 20)
 #endif
 constexpr int64_t GRID_CAP = HOTK_GRID_CAP;
-#ifndef HOTK_MINW
-#define HOTK_MINW 1
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // per-graph sums (forward): wave per (graph, row chunk); rows are consecutive, two coalesced loads per row
@@ -363,7 +357,7 @@ __device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* 
   pipeline4<2>((int)(rb - ra), load, use);
 }
 
-__global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+__global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
@@ -378,18 +372,30 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_fwd(A a, float* __r
     graphsum_rows<true>(L, a, stage, b, r0, rm, kv);
     graphsum_rows<false>(L, a, stage, b, rm, r1, kv);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) kvg_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, kv[s]);
+    for (int s = 0; s < 4; ++s) part_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, kv[s]);
   }
 }
 
-// out[b][x] = sum_k part[b*cpg + k][x], x over 4*9*64 floats
-__global__ void k_graph_reduce(const float* __restrict__ part, float* __restrict__ out, int64_t B, int cpg) {
-  const int64_t X = 4 * (NC + 1) * 64, total = B * X;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    int64_t b = t / X, x = t - b * X;
-    float s = 0.f;
-    for (int k = 0; k < cpg; ++k) s += part[((int64_t)b * cpg + k) * X + x];
-    out[t] = s;
+// out[b][s][c][lane] = sum_k part[b*cpg + k][s][c][lane] for c < 9 (fixed order: deterministic), followed by the
+// rotated copy  out[b][s][9 + k][(h, x)] = out[b][s][cidx(x)][(h, (x - k) & 15)]
+__global__ void k_graph_reduce(const float* __restrict__ part, float* __restrict__ out, int64_t B, int cpg, int dup) {
+  const int64_t X = (NC + 1) * 64;
+  for (int64_t bs = blockIdx.x; bs < B * 4; bs += gridDim.x) {
+    const int64_t b = bs >> 2;
+    const int s = (int)(bs & 3);
+    float* o = out + bs * KVG_C * 64;
+    for (int64_t x = threadIdx.x; x < X; x += blockDim.x) {
+      float acc = 0.f;
+      for (int k = 0; k < cpg; ++k) acc += part[(((int64_t)b * cpg + k) * 4 + s) * X + x];
+      o[x] = acc;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < NM * 64; t += blockDim.x) {
+      const int k = t >> 6, lane = t & 63, h = lane >> 4, xx = lane & 15;
+      const int cidx = dup ? (xx & 7) : (xx < NC ? xx : NC);
+      o[(NC + 1 + k) * 64 + lane] = o[cidx * 64 + h * 16 + ror_src(xx, k)];
+    }
+    __syncthreads();
   }
 }
 
@@ -415,24 +421,15 @@ __device__ __forceinline__ ColBlock col_block(const Lane& L, const A& a, int32_t
 }
 
 // two coalesced loads for entry e = (i, j) of a column segment: key slots {2p, 2p+1} of node i and the value
-// slots {2p | 2p+1} where the transposed slot is read from row te (zeros when the transposed entry is absent)
+// slots {2p | 2p+1} where the transposed slot is read from row te
 template <int P>
 __device__ __forceinline__ void load_kv2(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[2]) {
   r[0] = a.h1[(int64_t)i * a.ld_h1 + (K1 + 2 * P) * SLOT + L.lane];
   const bool lo = L.lane < 32;
   const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
-  // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time
-  // (t_scale): selecting on the loaded value here would make the prefetch synchronous
+  // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time:
+  // selecting on the loaded value here would make the prefetch synchronous
   r[1] = a.v[(int64_t)(row < 0 ? e : row) * a.ld_v + 2 * P * SLOT + L.lane];
-}
-
-// KV accumulate whose value channels are scaled by s (0 when the transposed entry is absent): the normaliser
-// channel still counts the key (kernelattncoef.py:103-122 sums keys over every entry of the column)
-__device__ __forceinline__ void kv_acc_scaled(float (&kv)[NC + 1], float phi, const float (&val)[NC], float s) {
-  const float ps = phi * s;
-#pragma unroll
-  for (int c = 0; c < NC; ++c) kv[c] = fmaf(ps, val[c], kv[c]);
-  kv[NC] += phi;
 }
 
 template <int P, class F>
@@ -466,37 +463,44 @@ __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float*
 }
 
 template <int P>
-__global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_fwd(A a) {
+__global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
+  __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
+  float* kvbuf = kvbuf_all[threadIdx.x >> 6];
   for (int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
-    float kv[2][NC + 1];
-    seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+    float rot0[NM], rot1[NM];
+    {
+      float kv[2][NC + 1];
+      seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+      kv_to_rot<false>(L, kvbuf, kv[0], rot0);
+      kv_to_rot<false>(L, kvbuf, kv[1], rot1);
+    }
     if (P == 0) {
       // node queries: terms 1, 2 (column sums) and 7, 8 (graph sums) go to the node's diagonal row
-      const float* kvg = a.kvg + (n / a.Nmax) * 4 * (NC + 1) * 64;
-      float g0[NC + 1], g1[NC + 1];
+      const int64_t b = n / a.Nmax;
       const float* q = a.h1 + n * a.ld_h1;
       float* o = a.att + (int64_t)a.diag_pos[n] * a.ld_att;
       float r[2] = {q[L.lane], q[64 + L.lane]};
-      kvg_load(L, kvg + 0 * (NC + 1) * 64, g0);
-      kvg_load(L, kvg + 1 * (NC + 1) * 64, g1);
+      float g0[NM], g1[NM];
+      kvg_load_rot(L, kvg_slot(a.kvg, b, 0), g0);
+      kvg_load_rot(L, kvg_slot(a.kvg, b, 1), g1);
       stage_put<2>(L, stage, r);
       float x[8];
-      slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[0], o + 0 * SLOT);
-      slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[1], o + 1 * SLOT);
-      slice8(L, stage + 2 * SLOT, x); apply_fwd_x(L, x, g0, o + 6 * SLOT);
-      slice8(L, stage + 3 * SLOT, x); apply_fwd_x(L, x, g1, o + 7 * SLOT);
+      slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 0 * SLOT);
+      slice8(L, stage + 1 * SLOT, x); apply_fwd(L, x, rot1, o + 1 * SLOT);
+      slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 6 * SLOT);
+      slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 7 * SLOT);
       zero_slots(L, o + 2 * SLOT, 4);
       zero_slots(L, o + 8 * SLOT, 2);
     } else if (P == 1) {
       // entries of column n: terms 3, 5 (this node's sums) and 9, 10 (graph sums)
-      const float* kvg = a.kvg + (n / a.Nmax) * 4 * (NC + 1) * 64;
-      float g0[NC + 1], g1[NC + 1];
-      kvg_load(L, kvg + 2 * (NC + 1) * 64, g0);
-      kvg_load(L, kvg + 3 * (NC + 1) * 64, g1);
+      const int64_t b = n / a.Nmax;
+      float g0[NM], g1[NM];
+      kvg_load_rot(L, kvg_slot(a.kvg, b, 2), g0);
+      kvg_load_rot(L, kvg_slot(a.kvg, b, 3), g1);
       const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
       for (int32_t base = c0; base < c1; base += 64) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
@@ -511,10 +515,10 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_fwd(A a) {
           float* o = a.att + (int64_t)rl(cb.e, k) * a.ld_att;
           stage_put<2>(L, stage, r);
           float x[8];
-          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[0], o + 2 * SLOT);
-          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[1], o + 4 * SLOT);
-          slice8(L, stage + 2 * SLOT, x); apply_fwd_x(L, x, g0, o + 8 * SLOT);
-          slice8(L, stage + 3 * SLOT, x); apply_fwd_x(L, x, g1, o + 9 * SLOT);
+          slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 2 * SLOT);
+          slice8(L, stage + 1 * SLOT, x); apply_fwd(L, x, rot1, o + 4 * SLOT);
+          slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 8 * SLOT);
+          slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 9 * SLOT);
           o[L.lane] = 0.f;                 // terms 1, 2 live on the diagonal only
           o[6 * SLOT + L.lane] = 0.f;      // terms 7, 8 too
         };
@@ -536,8 +540,8 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_fwd(A a) {
           float* o = a.att + (int64_t)e * a.ld_att;
           stage_put<1>(L, stage, r);
           float x[8];
-          slice8(L, stage + 0 * SLOT, x); apply_fwd_x(L, x, kv[0], o + 3 * SLOT);
-          slice8(L, stage + 1 * SLOT, x); apply_fwd_x(L, x, kv[1], o + 5 * SLOT);
+          slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 3 * SLOT);
+          slice8(L, stage + 1 * SLOT, x); apply_fwd(L, x, rot1, o + 5 * SLOT);
         };
         pipeline4<1>(cnt, load, use);
       }
@@ -548,9 +552,22 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_fwd(A a) {
 // ------------------------------------------------------------------------------------------------
 // per-graph terms (backward): (1) query side + dKVg partials, (2) key/value side
 // ------------------------------------------------------------------------------------------------
+// rows [ra, rb) of graph b, all diagonal or all off-diagonal, against the two per-graph sums kv0 / kv1 of that kind
 template <bool DIAG>
-__device__ __forceinline__ void graph_apply_bwd_rows(const Lane& L, const A& a, float* stage, int64_t b, int64_t ra,
-                                                     int64_t rb, const float (&kv)[4][NC + 1], float (&dkv)[4][NC + 1]) {
+__device__ __forceinline__ void graph_apply_bwd_rows(const LaneB& L, const A& a, float* stage, int64_t b, int64_t ra,
+                                                     int64_t rb, float* __restrict__ dst) {
+  if (rb <= ra) {
+    float z[NC + 1];
+#pragma unroll
+    for (int c = 0; c <= NC; ++c) z[c] = 0.f;
+    part_store(L, dst + (DIAG ? 0 : 2) * (NC + 1) * 64, z);
+    part_store(L, dst + (DIAG ? 1 : 3) * (NC + 1) * 64, z);
+    return;
+  }
+  float kv[2][NC + 1], dkv[2][NC + 1];
+  kvg_load(L, kvg_slot(a.kvg, b, DIAG ? 0 : 2), kv[0]);
+  kvg_load(L, kvg_slot(a.kvg, b, DIAG ? 1 : 3), kv[1]);
+  kv_zero<2>(dkv);
   auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
     const float* g = a.datt + row * a.ld_datt;
@@ -570,16 +587,18 @@ __device__ __forceinline__ void graph_apply_bwd_rows(const Lane& L, const A& a, 
     float* dq = DIAG ? a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 2 * SLOT
                      : a.dh2 + row * a.ld_dh2 + 4 * SLOT;
     slice8(L, stage, x); slice8(L, stage + 64, g);
-    apply_bwd_x(L, x, kv[DIAG ? 0 : 2], g, dq, dkv[DIAG ? 0 : 2]);
+    apply_bwd(L, x, kv[0], g, dq, dkv[0]);
     slice8(L, stage + 32, x); slice8(L, stage + 96, g);
-    apply_bwd_x(L, x, kv[DIAG ? 1 : 3], g, dq + SLOT, dkv[DIAG ? 1 : 3]);
+    apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
   };
   pipeline4<2>((int)(rb - ra), load, use);
+  part_store(L, dst + (DIAG ? 0 : 2) * (NC + 1) * 64, dkv[0]);
+  part_store(L, dst + (DIAG ? 1 : 3) * (NC + 1) * 64, dkv[1]);
 }
 
-__global__ __launch_bounds__(TPB, HOTK_MINW) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+__global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
-  const Lane L = make_lane(a.proj);
+  const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
   for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
@@ -587,24 +606,70 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_graph_apply_bwd(A a, float* 
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
     const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
-    float kv[4][NC + 1], dkv[4][NC + 1];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kvg_load(L, a.kvg + ((int64_t)b * 4 + s) * (NC + 1) * 64, kv[s]);
-    kv_zero<4>(dkv);
-    graph_apply_bwd_rows<true>(L, a, stage, b, r0, rm, kv, dkv);
-    graph_apply_bwd_rows<false>(L, a, stage, b, rm, r1, kv, dkv);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kvg_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, dkv[s]);
+    float* d = dst + (int64_t)w * 4 * (NC + 1) * 64;
+    graph_apply_bwd_rows<true>(L, a, stage, b, r0, rm, d);
+    graph_apply_bwd_rows<false>(L, a, stage, b, rm, r1, d);
   }
 }
 
-// wave per chunk of 16 consecutive rows of one graph
+// key / value side of the per-graph sums: rows [ra, rb) of one kind against dKVg slots (s0, s1)
 constexpr int GB_ROWS = 16;
-__global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_bwd(A a) {
-  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
-  const Lane L = make_lane(a.proj);
-  float* stage = stage_all[threadIdx.x >> 6];
+template <bool DIAG>
+__device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, float* stage, int64_t b, int64_t ra,
+                                                  int64_t rb) {
+  if (rb <= ra) return;
   const bool lo = L.lane < 32;
+  float d0[NC + 1], d1[NC + 1], t0[NM], t1[NM];
+  kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), d0);
+  kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), d1);
+  kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), t0);
+  kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), t1);
+  auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
+    const int64_t row = ra + k;
+    const float* vr = a.v + row * a.ld_v;
+    if (DIAG) {
+      const int64_t n = b * a.Nmax + (row - b * a.Emax);
+      r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
+      r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];
+    } else {
+      r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+      r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];
+    }
+    r[2] = (a.dout && L.lane < a.D) ? a.dout[row * a.ld_dout + L.lane] : 0.f;
+  };
+  auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
+    const int64_t row = ra + k;
+    stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
+    float* dvr = a.dv + row * a.ld_dv;
+    float* dh2r = a.dh2 + row * a.ld_dh2;
+    float x[8], val[8];
+    if (DIAG) {
+      float* dkn = a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 10 * SLOT;
+      slice8(L, stage, x); slice8(L, stage + 64, val);
+      kv_bwd(L, x, val, d0, t0, dvr + 6 * SLOT, dkn);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+      kv_bwd(L, x, val, d1, t1, dvr + 8 * SLOT, dkn + SLOT);
+      if (lo) { dvr[7 * SLOT + L.lane] = 0.f; dvr[9 * SLOT + L.lane] = 0.f; }
+      zero_slots(L, dh2r, 8);   // entry-level queries / keys are masked on the diagonal
+    } else {
+      slice8(L, stage, x); slice8(L, stage + 64, val);
+      kv_bwd(L, x, val, d0, t0, dvr + 7 * SLOT, dh2r + K2 * SLOT);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+      kv_bwd(L, x, val, d1, t1, dvr + 9 * SLOT, dh2r + (K2 + 1) * SLOT);
+      if (lo) { dvr[6 * SLOT + L.lane] = 0.f; dvr[8 * SLOT + L.lane] = 0.f; }
+    }
+    // skip path: d h2[:, 8 slots:] = d out (zero when the caller routes that gradient elsewhere)
+    if (L.lane < a.D) dh2r[8 * SLOT + L.lane] = r[2];
+    for (int i = 64 + L.lane; i < a.D; i += 64) dh2r[8 * SLOT + i] = a.dout ? a.dout[row * a.ld_dout + i] : 0.f;
+  };
+  pipeline4<3>((int)(rb - ra), load, use);
+}
+
+// wave per chunk of 16 consecutive rows of one graph
+__global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
+  const LaneB L = make_lane_b(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
   const int64_t cpg = (a.Emax + GB_ROWS - 1) / GB_ROWS;
   const int64_t nwork = a.B * cpg;
   for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
@@ -612,50 +677,9 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_bwd(A a) {
     chunk_rows(a, w, (int)cpg, GB_ROWS, &b, &r0, &r1);
     if (r1 <= r0) continue;
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
-    const float* dkvg = a.dkvg + b * 4 * (NC + 1) * 64;
-    float d[4][NC + 1];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kvg_load(L, dkvg + s * (NC + 1) * 64, d[s]);
-    auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
-      const int64_t row = r0 + k;
-      const float* vr = a.v + row * a.ld_v;
-      if (row < nodes_end) {
-        const int64_t n = b * a.Nmax + (row - b * a.Emax);
-        r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
-        r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];
-      } else {
-        r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
-        r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];
-      }
-      r[2] = (a.dout && L.lane < a.D) ? a.dout[row * a.ld_dout + L.lane] : 0.f;
-    };
-    auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
-      const int64_t row = r0 + k;
-      const bool diag = row < nodes_end;
-      stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
-      float* dvr = a.dv + row * a.ld_dv;
-      float* dh2r = a.dh2 + row * a.ld_dh2;
-      float x[8], val[8];
-      if (diag) {
-        float* dkn = a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 10 * SLOT;
-        slice8(L, stage, x); slice8(L, stage + 64, val);
-        kv_bwd_x(L, x, val, d[0], dvr + 6 * SLOT, dkn);
-        slice8(L, stage + 32, x); slice8(L, stage + 96, val);
-        kv_bwd_x(L, x, val, d[2], dvr + 8 * SLOT, dkn + SLOT);
-        if (lo) { dvr[7 * SLOT + L.lane] = 0.f; dvr[9 * SLOT + L.lane] = 0.f; }
-        zero_slots(L, dh2r, 8);   // entry-level queries / keys are masked on the diagonal
-      } else {
-        slice8(L, stage, x); slice8(L, stage + 64, val);
-        kv_bwd_x(L, x, val, d[1], dvr + 7 * SLOT, dh2r + K2 * SLOT);
-        slice8(L, stage + 32, x); slice8(L, stage + 96, val);
-        kv_bwd_x(L, x, val, d[3], dvr + 9 * SLOT, dh2r + (K2 + 1) * SLOT);
-        if (lo) { dvr[6 * SLOT + L.lane] = 0.f; dvr[8 * SLOT + L.lane] = 0.f; }
-      }
-      // skip path: d h2[:, 8 slots:] = d out (zero when the caller routes that gradient elsewhere)
-      if (L.lane < a.D) dh2r[8 * SLOT + L.lane] = r[2];
-      for (int i = 64 + L.lane; i < a.D; i += 64) dh2r[8 * SLOT + i] = a.dout ? a.dout[row * a.ld_dout + i] : 0.f;
-    };
-    pipeline4<3>((int)(r1 - r0), load, use);
+    const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
+    graphsum_bwd_rows<true>(L, a, stage, b, r0, rm);
+    graphsum_bwd_rows<false>(L, a, stage, b, rm, r1);
   }
 }
 
@@ -663,69 +687,77 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_graphsum_bwd(A a) {
 // node segments (backward): one wave per (node, part), same split as the forward
 // ------------------------------------------------------------------------------------------------
 template <int P>
-__global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_bwd(A a) {
+__global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
-  const Lane L = make_lane(a.proj);
+  __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
+  const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
+  float* kvbuf = kvbuf_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
   for (int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
-    float kv[2][NC + 1], dkv[2][NC + 1];
-    seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+    float dkv[2][NC + 1];
     kv_zero<2>(dkv);
-    if (P == 0) {  // node queries (terms 1, 2)
-      const int64_t dr = a.diag_pos[n];
-      float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[dr * a.ld_datt + L.lane]};
-      float* dq = a.dh1 + n * a.ld_dh1;
-      stage_put<2>(L, stage, r);
-      float x[8], g[8];
-      slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
-      slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
-    } else if (P == 1) {  // entries of column n (terms 3, 5)
-      const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
-      for (int32_t base = c0; base < c1; base += 64) {
-        const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-        const ColBlock cb = col_block(L, a, base, cnt);
-        auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
-          const int64_t e = rl(cb.e, k);
-          r[0] = a.h2[e * a.ld_h2 + L.lane];                                      // query slots 0, 1
-          r[1] = a.datt[e * a.ld_datt + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
-        };
-        auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
-          if (rl(cb.kd, k) != 2) return;
-          float* dq = a.dh2 + (int64_t)rl(cb.e, k) * a.ld_dh2;
-          stage_put<2>(L, stage, r);
-          float x[8], g[8];
-          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
-          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
-        };
-        pipeline4<2>(cnt, load, use);
-      }
-    } else {  // entries of row n (terms 4, 6)
-      const int32_t c0 = a.row_ptr[n], c1 = a.row_ptr[n + 1];
-      for (int32_t base = c0; base < c1; base += 64) {
-        const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
-        const int32_t rec = L.lane < cnt ? a.row_rec[base + L.lane] : -1;
-        auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
-          const int32_t e_ = rl(rec, k);
-          const int64_t e = e_ < 0 ? ~e_ : e_;
-          r[0] = a.h2[e * a.ld_h2 + 2 * SLOT + L.lane];                            // query slots 2, 3
-          r[1] = a.datt[e * a.ld_datt + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
-        };
-        auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
-          const int32_t e = rl(rec, k);
-          if (e < 0) return;
-          float* dq = a.dh2 + (int64_t)e * a.ld_dh2 + 2 * SLOT;
-          stage_put<2>(L, stage, r);
-          float x[8], g[8];
-          slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd_x(L, x, kv[0], g, dq, dkv[0]);
-          slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd_x(L, x, kv[1], g, dq + SLOT, dkv[1]);
-        };
-        pipeline4<2>(cnt, load, use);
+    {
+      float kv[2][NC + 1];
+      seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+      if (P == 0) {  // node queries (terms 1, 2)
+        const int64_t dr = a.diag_pos[n];
+        float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[dr * a.ld_datt + L.lane]};
+        float* dq = a.dh1 + n * a.ld_dh1;
+        stage_put<2>(L, stage, r);
+        float x[8], g[8];
+        slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
+        slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
+      } else if (P == 1) {  // entries of column n (terms 3, 5)
+        const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
+        for (int32_t base = c0; base < c1; base += 64) {
+          const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+          const ColBlock cb = col_block(L, a, base, cnt);
+          auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+            const int64_t e = rl(cb.e, k);
+            r[0] = a.h2[e * a.ld_h2 + L.lane];                                      // query slots 0, 1
+            r[1] = a.datt[e * a.ld_datt + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
+          };
+          auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+            if (rl(cb.kd, k) != 2) return;
+            float* dq = a.dh2 + (int64_t)rl(cb.e, k) * a.ld_dh2;
+            stage_put<2>(L, stage, r);
+            float x[8], g[8];
+            slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
+            slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
+          };
+          pipeline4<2>(cnt, load, use);
+        }
+      } else {  // entries of row n (terms 4, 6)
+        const int32_t c0 = a.row_ptr[n], c1 = a.row_ptr[n + 1];
+        for (int32_t base = c0; base < c1; base += 64) {
+          const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+          const int32_t rec = L.lane < cnt ? a.row_rec[base + L.lane] : -1;
+          auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+            const int32_t e_ = rl(rec, k);
+            const int64_t e = e_ < 0 ? ~e_ : e_;
+            r[0] = a.h2[e * a.ld_h2 + 2 * SLOT + L.lane];                            // query slots 2, 3
+            r[1] = a.datt[e * a.ld_datt + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
+          };
+          auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
+            const int32_t e = rl(rec, k);
+            if (e < 0) return;
+            float* dq = a.dh2 + (int64_t)e * a.ld_dh2 + 2 * SLOT;
+            stage_put<2>(L, stage, r);
+            float x[8], g[8];
+            slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
+            slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, g); apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
+          };
+          pipeline4<2>(cnt, load, use);
+        }
       }
     }
     // key / value side of this part's two column sums: dV of the plain slot goes to row e, dV of the transposed
     // slot to row te; d(raw key) contributions go to ck[e] (summed per row node afterwards)
+    float drot0[NM], drot1[NM];
+    kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
+    kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
     for_col_entries<P>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te) __attribute__((always_inline)) {
       float* dve = a.dv + (int64_t)e * a.ld_dv;
       float* dvt = te >= 0 ? a.dv + (int64_t)te * a.ld_dv : nullptr;
@@ -739,13 +771,13 @@ __global__ __launch_bounds__(TPB, HOTK_MINW) void k_seg_bwd(A a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      kv_bwd_x(L, x, val, dkv[0], d0, ck);
+      kv_bwd(L, x, val, dkv[0], drot0, d0, ck);
       slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
       if (P != 2 && te < 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      kv_bwd_x(L, x, val, dkv[1], d1, ck + SLOT);
+      kv_bwd(L, x, val, dkv[1], drot1, d1, ck + SLOT);
       if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
     });
   }
@@ -765,22 +797,21 @@ int check_args(const A* a) {
   return HOTK_OK;
 }
 
-void chunking(const A* a, int* cpg, int* rows) {
-  int64_t c = (a->Emax + 63) / 64;
+void chunking(int64_t Emax, int* cpg, int* rows) {
+  int64_t c = (Emax + 63) / 64;
   if (c > 4096) c = 4096;
   if (c < 1) c = 1;
   *cpg = (int)c;
-  *rows = (int)((a->Emax + c - 1) / c);
+  *rows = (int)((Emax + c - 1) / c);
 }
 
 }  // namespace
 
 extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes) {
   HOTK_CHECK_ARG(bytes && B >= 0 && Emax >= 0);
-  int64_t c = (Emax + 63) / 64;
-  if (c > 4096) c = 4096;
-  if (c < 1) c = 1;
-  *bytes = (size_t)B * c * 4 * (NC + 1) * 64 * sizeof(float);
+  int cpg, rows;
+  chunking(Emax, &cpg, &rows);
+  *bytes = (size_t)B * cpg * 4 * (NC + 1) * 64 * sizeof(float);
   return HOTK_OK;
 }
 
@@ -791,16 +822,14 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
   int cpg, rows;
-  chunking(a, &cpg, &rows);
+  chunking(a->Emax, &cpg, &rows);
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
-  if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
-  float* part = cpg > 1 ? (float*)workspace : a->kvg;
+  if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
+  float* part = (float*)workspace;
   unsigned g1 = hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP);
   hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
-  if (cpg > 1)
-    hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->kvg,
-                       a->B, cpg);
+  hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4, 1, 256 * 16)), dim3(256), 0, st, part, a->kvg, a->B, cpg, 0);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   hipLaunchKernelGGL(k_seg_fwd<1>, gseg, dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_seg_fwd<2>, gseg, dim3(TPB), 0, st, *a);
@@ -819,16 +848,14 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
   int cpg, rows;
-  chunking(a, &cpg, &rows);
+  chunking(a->Emax, &cpg, &rows);
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
-  if (cpg > 1 && (!workspace || ws_bytes < need)) return HOTK_EWORKSPACE;
-  float* part = cpg > 1 ? (float*)workspace : a->dkvg;
+  if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
+  float* part = (float*)workspace;
   hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
-  if (cpg > 1)
-    hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4 * (NC + 1) * 64, 256)), dim3(256), 0, st, part, a->dkvg,
-                       a->B, cpg);
-  hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->R, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4, 1, 256 * 16)), dim3(256), 0, st, part, a->dkvg, a->B, cpg, 1);
+  hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(TPB), 0, st, *a);

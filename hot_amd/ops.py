@@ -483,7 +483,7 @@ class AttnCore22(Function):
         proj = proj.contiguous().float()
         padded = plan.Ev != plan.R
         att = (torch.zeros if padded else torch.empty)(plan.R, 320, dtype=torch.float32, device=dev)
-        kvg = torch.empty(plan.B, 4, 9, 64, dtype=torch.float32, device=dev)
+        kvg = torch.empty(plan.B, 4, 25, 64, dtype=torch.float32, device=dev)
         a = AttnCore22._args(plan, h1, h2, v, proj, D)
         a.att, a.ld_att, a.kvg = att.data_ptr(), 320, kvg.data_ptr()
         ws, nws = AttnCore22._workspace(plan, dev)

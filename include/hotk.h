@@ -187,10 +187,11 @@ int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const
  *   v   [R,  >=10*32]  fc_v output (padding rows are ignored, they need not be zero)
  *   att [R,  >=10*32]  the ten attention terms in the reference's concatenation order; valid rows are fully
  *                      written, padding rows are left untouched (caller zero-fills when the batch has padding)
- *   kvg [B,4,9,64]     per-graph sums (saved for the backward pass)
+ *   kvg [B,4,25,64]    per-graph sums (saved for the backward pass): per slot 9 feature-major channels + 16 rotated
+ *                      channel-major copies (see csrc/fused22.hip)
  * backward: datt [R,10*32] -> dh1 [Nn,12*32] (key slots 4..9 are NOT written here: they are the row-segment sum of
  * ck [R,6*32], hotk_seg_sum_rows over the row CSR), dh2 [R, 8*32 (+D)] (skip-path columns = dout when given,
- * zero otherwise), dv [R,10*32]; padding rows of dh1/dh2/dv are left untouched.  dkvg [B,4,9,64] scratch.
+ * zero otherwise), dv [R,10*32]; padding rows of dh1/dh2/dv are left untouched.  dkvg [B,4,25,64] scratch.
  * workspace: hotk_attn22_workspace_bytes(B, Emax) (per-chunk partial graph sums).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct hotk_attn22_args {

@@ -19,7 +19,7 @@ h2 = torch.randn(plan.R, 288, device=dev)
 v = torch.randn(plan.R, 320, device=dev)
 proj = torch.randn(16, 8, device=dev)
 att = torch.empty(plan.R, 320, device=dev)
-kvg = torch.empty(plan.B, 4, 9, 64, device=dev)
+kvg = torch.empty(plan.B, 4, 25, 64, device=dev)
 datt = torch.randn(plan.R, 320, device=dev)
 dout = torch.randn(plan.R, 32, device=dev)
 dh1 = torch.empty(plan.Nn, 384, device=dev); dh2 = torch.empty(plan.R, 288, device=dev)

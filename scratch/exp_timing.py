@@ -11,7 +11,7 @@ dev = torch.device('cuda', 0)
 G = bench.make_inputs(int(round(entries / 654)), dev, 1234)
 plan = G.plan
 h1 = torch.randn(plan.Nn, 384, device=dev); h2 = torch.randn(plan.R, 288, device=dev); v = torch.randn(plan.R, 320, device=dev)
-proj = torch.randn(16, 8, device=dev); att = torch.empty(plan.R, 320, device=dev); kvg = torch.empty(plan.B, 4, 9, 64, device=dev)
+proj = torch.randn(16, 8, device=dev); att = torch.empty(plan.R, 320, device=dev); kvg = torch.empty(plan.B, 4, 25, 64, device=dev)
 ck = torch.zeros(plan.R, 192, device=dev)
 a = ops.AttnCore22._args(plan, h1, h2, v, proj, 32)
 a.att, a.ld_att, a.kvg, a.ck = att.data_ptr(), 320, kvg.data_ptr(), ck.data_ptr()

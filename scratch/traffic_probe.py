@@ -23,7 +23,7 @@ del a, b, a1, b1
 G = bench.make_inputs(int(round(entries / 654)), dev, 1234)
 plan = G.plan
 h1 = torch.randn(plan.Nn, 384, device=dev); h2 = torch.randn(plan.R, 288, device=dev); v = torch.randn(plan.R, 320, device=dev)
-proj = torch.randn(16, 8, device=dev); att = torch.empty(plan.R, 320, device=dev); kvg = torch.empty(plan.B, 4, 9, 64, device=dev)
+proj = torch.randn(16, 8, device=dev); att = torch.empty(plan.R, 320, device=dev); kvg = torch.empty(plan.B, 4, 25, 64, device=dev)
 datt = torch.randn(plan.R, 320, device=dev); dout = torch.randn(plan.R, 32, device=dev)
 dh1 = torch.empty(plan.Nn, 384, device=dev); dh2 = torch.empty(plan.R, 288, device=dev)
 dv = torch.empty(plan.R, 320, device=dev); ck = torch.empty(plan.R, 192, device=dev); dkvg = torch.empty_like(kvg)
