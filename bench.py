@@ -100,6 +100,9 @@ def main():
     ap.add_argument('--profile-kernel', default='auto', help='C-ABI entry point timed live with HIP events')
     args = ap.parse_args()
 
+    if os.environ.get('HOTK_BENCH_DEBUG'):
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ['HOTK_BENCH_DEBUG']), exit=True)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -107,8 +110,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        # one rank per GPU over RCCL; HOTK_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs
+        backend = os.environ.get('HOTK_BENCH_BACKEND', 'nccl')
+        local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        else:
+            dist.init_process_group(backend)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 

@@ -28,6 +28,18 @@ def partition_graphs(sizes: Sequence[int], world: int) -> List[Tuple[int, int]]:
     return [(cuts[i], cuts[i + 1]) for i in range(world)]
 
 
+def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    """all_reduce in place; a gloo group (CPU rehearsal of the multi-GPU path) gets device tensors staged through
+    the host, since gloo collectives on HIP tensors are not usable on this stack."""
+    if t.is_cuda and dist.get_backend(group) == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, average: bool = False) -> None:
     """Sum (or average) the gradients of `params` over the group with ONE collective on a flat bucket
     (the C1 layer has 80 k parameters = 320 KB: latency-bound, so a single call beats per-tensor calls).
@@ -36,7 +48,7 @@ def allreduce_gradients(params: Iterable[torch.nn.Parameter], group=None, averag
     if not params or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1) for p in params])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    _all_reduce(flat, dist.ReduceOp.SUM, group)
     if average:
         flat /= dist.get_world_size(group)
     ofs = 0
@@ -55,5 +67,5 @@ def max_over_ranks(value: float, device, group=None) -> float:
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return float(value)
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    _all_reduce(t, dist.ReduceOp.MAX, group)
     return float(t.item())
