@@ -29,6 +29,10 @@ D, DQK, DV, HEADS = 32, 32, 32, 4
 # per-node term 2*4*12*dqk + 3*2*2*4*S*H*m*(dvh+1) (S=2, H=4, m=16, dvh=8) amortised over entries/node
 BYTES_PER_ENTRY = 96 * DQK + 224 * DV + 50
 BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEADS + 1)
+# HBM traffic of the fused core per valid entry on THIS workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
+# profiles/r01_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at 10 M entries
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4688, 'hotk_attn22_backward': 7928}
 
 
 def build_structure(n_graphs, distinct=512, seed=1234):
@@ -179,11 +183,15 @@ def main():
         if prof_name and prof_name in timed:
             tot_ms, calls, alg_bytes = timed[prof_name]
             ach = alg_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+            traffic = PMC_TRAFFIC_BYTES_PER_ENTRY.get(prof_name)
             roof = {'bound': 'hbm', 'kernel': prof_name, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
-                    'frac': ach * 1e9 / HBM_PEAK, 'traffic': None, 'launches': calls,
+                    'frac': ach * 1e9 / HBM_PEAK, 'traffic': None if traffic is None else traffic * n_entries,
+                    'traffic_source': 'profiles/r01_pmc_traffic_attn22.txt (bytes per launch = measured B/entry x entries)',
+                    'launches': calls,
                     'avg_launch_ms': tot_ms / max(calls, 1),
                     'note': 'achieved = algorithmic bytes (operands read once + results written once) of the '
-                            'dominant C-ABI kernel / its HIP-event time inside the timed region'}
+                            'dominant C-ABI kernel / its HIP-event time inside the timed region; the kernel is '
+                            'VALU-bound (fp32 vector ALU 55-70 % busy, HBM traffic 1.15x algorithmic), see DESIGN.md 5'}
         line = {
             'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': value, 'unit': 'entries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,

@@ -666,7 +666,7 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
 }
 
 // wave per chunk of 16 consecutive rows of one graph
-__global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
+__global__ __launch_bounds__(TPB, 3) void k_graphsum_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
