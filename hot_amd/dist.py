@@ -1,8 +1,17 @@
-"""Multi-GPU helpers for the graph-minibatch mode: graphs are independent units, so the layer
-needs no exchange in forward or backward; only parameter gradients cross GPUs (one flat all-reduce over RCCL,
-`backend="nccl"` on ROCm).  Stands in for the Lightning DDPPlugin of regression/main/entry.py:110-113.
+"""Multi-GPU helpers.  One process per GPU; `backend="nccl"` is RCCL on ROCm.
 
-One process per GPU; every function takes the process group explicitly or uses the default one."""
+Graph-minibatch mode: graphs are independent units, so the layer needs no exchange in forward or backward; only
+parameter gradients cross GPUs (one flat all-reduce).  Stands in for the Lightning DDPPlugin of
+regression/main/entry.py:110-113.
+
+Edge-shard mode (one giant graph): every rank holds ALL nodes (diagonal entries, N << E) and a share of the
+off-diagonal entries in which (i,j) and (j,i) are co-located (`shard_graph`).  Node-level work is replicated; the
+only exchanges are all-reduces of the key-value summaries built from entries (per-node and per-graph
+sum phi(K) (x) [V|1] in forward, their gradients in backward) and the final parameter-gradient all-reduce.
+Replicated diagonal entries enter entry-level sums with weight 1/world (exact for power-of-two worlds) so that the
+reduced sums count them once; the caller weights replicated output rows by `ShardInfo.entry_weight` in its loss.
+
+Every function takes the process group explicitly or uses the default one."""
 from typing import Iterable, List, Sequence, Tuple
 
 import numpy as np
@@ -69,3 +78,36 @@ def max_over_ranks(value: float, device, group=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     _all_reduce(t, dist.ReduceOp.MAX, group)
     return float(t.item())
+
+
+class ShardInfo:
+    """Edge-shard context attached to a Plan (`plan.shard`): ops that sum over entries all-reduce their summaries."""
+
+    def __init__(self, rank: int, world: int, entry_weight: torch.Tensor, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.entry_weight = entry_weight      # [R] fp32: 1/world on diagonal rows, 1 on off-diagonal rows, 0 on padding
+
+    def all_reduce_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            _all_reduce(t, dist.ReduceOp.SUM, self.group)
+        return t
+
+
+def shard_owner(i: torch.Tensor, j: torch.Tensor, world: int) -> torch.Tensor:
+    """owner rank of off-diagonal entry (i,j): a function of the unordered pair, so transposes stay together"""
+    lo, hi = torch.minimum(i, j), torch.maximum(i, j)
+    return (lo * 1000003 + hi * 7919) % world
+
+
+def shard_graph(node_feature: torch.Tensor, edge_index: torch.Tensor, edge_feature: torch.Tensor, world: int, rank: int,
+                group=None):
+    """Local Batch of `rank` for ONE graph given PyG-style (node_feature [N,Dv], edge_index [2,E], edge_feature [E,De]):
+    all N nodes + the owned edges (original order kept).  Returns (Batch, owned edge positions [E_local])."""
+    from .batch.sparse import make_batch_concatenated
+    own = (shard_owner(edge_index[0], edge_index[1], world) == rank).nonzero(as_tuple=True)[0]
+    G = make_batch_concatenated(node_feature, edge_index[:, own], edge_feature[own], [node_feature.size(0)], [own.numel()])
+    plan = G.plan
+    w = torch.where(plan.kind == 1, torch.full((plan.R,), 1.0 / world, device=plan.device),
+                    (plan.kind == 2).to(torch.float32))
+    plan.shard = ShardInfo(rank, world, w, group)
+    return G, own

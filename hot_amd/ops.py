@@ -360,15 +360,28 @@ class KernelAttn(Function):
                 sidx, seg_div = (plan.coln if dim1 == 2 else plan.rown), 1
             vsidx, vseg_div = plan.coln, 1
         kind_q, keep_q = (plan.nkind, KEEP_DIAG) if ord_q == 1 else (plan.kind, KEEP_OFFDIAG)
-        KV = seg_outer_sum(k, kidx, v, None, None, seg, HH, m, c)
+        # edge-shard mode (hot_amd.dist): sums over ENTRIES are partial on each rank and are all-reduced; diagonal
+        # entries are replicated on every rank and enter with weight 1/world.  Sums over nodes are replicated work.
+        shard = getattr(plan, 'shard', None)
+        reduce_kv = shard is not None and (diagonal is not None or ord_k == 2)
+        wv = aug = None
+        vw = v
+        if shard is not None and diagonal is not None:
+            wv = shard.entry_weight.view(-1, 1)
+            vw = v.reshape(nv, HH * c) * wv
+            aug = wv.expand(nv, HH).contiguous()
+        KV = seg_outer_sum(k, kidx, vw, None, aug, seg, HH, m, c)
+        if reduce_kv:
+            shard.all_reduce_(KV)
         out = row_contract(q, None, KV, sidx, seg_div, kind_q, keep_q, nq, HH, m, c, True)
-        ctx.save_for_backward(q, k, v, KV)
+        ctx.save_for_backward(q, k, vw, KV, aug, wv)
         ctx.cfg = (plan, ord_q, ord_k, HH, m, c, diagonal, nq, nk, nv, kidx, sidx, seg_div, vsidx, vseg_div, kind_q, keep_q)
+        ctx.vshape, ctx.reduce_kv = v.shape, reduce_kv
         return out.view(*q.shape[:-1], HH * c)
 
     @staticmethod
     def backward(ctx, dO):
-        q, k, v, KV = ctx.saved_tensors
+        q, k, v, KV, aug, wv = ctx.saved_tensors
         plan, ord_q, ord_k, HH, m, c, diagonal, nq, nk, nv, kidx, sidx, seg_div, vsidx, vseg_div, kind_q, keep_q = ctx.cfg
         dO = dO.contiguous()
         X, XA = apply_bwd_stats(q, KV, sidx, seg_div, kind_q, keep_q, dO, nq, HH, m, c)
@@ -381,14 +394,18 @@ class KernelAttn(Function):
         else:
             qseg = plan.col_seg() if diagonal[0] == 2 else plan.row_seg()
         dKV = seg_outer_sum(q, None, X, None, XA, qseg, HH, m, c)
+        if ctx.reduce_kv:
+            plan.shard.all_reduce_(dKV)       # backward of the forward all-reduce: every rank needs the full dKV
         kind_v = plan.nkind if (diagonal is None and ord_k == 1) else plan.kind
         dv = row_contract(k, kidx, dKV, vsidx, vseg_div, kind_v, KEEP_VALID, nv, HH, m, c, False)
-        dkc = row_expand(dKV, vsidx, vseg_div, v, None, None, kind_v, KEEP_VALID, nv, HH, m, c)
+        if wv is not None:
+            dv = dv * wv
+        dkc = row_expand(dKV, vsidx, vseg_div, v, None, aug, kind_v, KEEP_VALID, nv, HH, m, c)
         if diagonal is None:
             dk = dkc
         else:
             dk = seg_sum_rows(dkc, plan.row_seg())
-        return dq.view(q.shape), dk.view(k.shape), dv.view(v.shape), None, None, None, None, None, None
+        return dq.view(q.shape), dk.view(k.shape), dv.view(ctx.vshape), None, None, None, None, None, None
 
 
 def _ptr(t):

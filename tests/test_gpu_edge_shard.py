@@ -1,0 +1,118 @@
+"""GPU (-m gpu): edge-shard mode of ONE graph over two ranks.  Both ranks share cuda:0 and talk over
+gloo (host-staged collectives in hot_amd.dist stand in for RCCL, which needs one GPU per rank); the arithmetic on
+every rank is the HIP path.  Each rank checks its local outputs, its local input gradients and the all-reduced
+parameter gradients against the same layer run on the whole graph in one process."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
+
+
+def _graph(seed=3, n=300):
+    rng = np.random.default_rng(seed)
+    g = torch.Generator().manual_seed(seed)
+    und = set()
+    while len(und) < 1200:
+        i, j = rng.integers(0, n, 2)
+        if i != j:
+            und.add((int(min(i, j)), int(max(i, j))))
+    pairs = set()
+    for k, (i, j) in enumerate(sorted(und)):
+        pairs.add((i, j))
+        if k % 5:            # every fifth pair stays one-directional: entries without a transposed partner
+            pairs.add((j, i))
+    ei = torch.tensor(sorted(pairs), dtype=torch.long).t().contiguous()
+    return torch.randn(n, 16, generator=g), ei, torch.randn(ei.size(1), 16, generator=g), g
+
+
+def _layer():
+    from hot_amd.models.common import KernelFeatureMap
+    from hot_amd.models.sparse import KernelSelfAttn
+    torch.manual_seed(0)
+    return KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8, generalized_attention=True)).to(DEV)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        from hot_amd.batch import sparse as bs
+        from hot_amd.dist import shard_graph, allreduce_gradients
+        nf, ei, ef, g = _graph()
+        n, E = nf.size(0), ei.size(1)
+        Rw = torch.randn(n + E, 32, generator=g).to(DEV)          # loss weights per global row (nodes, then edges)
+        # whole graph in this process
+        layer = _layer()
+        layer.use_fused = False
+        G = bs.make_batch_concatenated(nf.to(DEV), ei.to(DEV), ef.to(DEV), [n], [E])
+        x = G.values.clone().requires_grad_(True)
+        y = layer(bs.batch_like(G, x, skip_masking=True))
+        (y.values[0] * Rw).sum().backward()
+        ref_y, ref_gx = y.values[0].detach(), x.grad[0].clone()
+        ref_gp = {k: p.grad.clone() for k, p in layer.named_parameters()}
+        # this rank's shard
+        layer2 = _layer()
+        Gs, own = shard_graph(nf.to(DEV), ei.to(DEV), ef.to(DEV), world, rank)
+        rows = torch.cat([torch.arange(n, device=DEV), n + own])         # global row of every local row
+        xs = Gs.values.clone().requires_grad_(True)
+        ys = layer2(bs.batch_like(Gs, xs, skip_masking=True))
+        w = Gs.plan.shard.entry_weight.view(-1, 1)
+        (ys.values[0] * Rw[rows] * w).sum().backward()
+        allreduce_gradients(layer2.parameters())
+        gx = xs.grad[0].clone()
+        gx_nodes = gx[:n].clone()
+        Gs.plan.shard.all_reduce_(gx_nodes)                        # replicated inputs: their gradient is the sum over ranks
+        res = {'n_local_edges': int(own.numel()),
+               'y': _rel(ys.values[0].detach(), ref_y[rows]),
+               'gx_edges': _rel(gx[n:], ref_gx[n + own]),
+               'gx_nodes': _rel(gx_nodes, ref_gx[:n]),
+               'gp': max(_rel(p.grad, ref_gp[k]) for k, p in layer2.named_parameters())}
+        q.put((rank, res))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_edge_shard_two_ranks_matches_whole_graph():
+    import torch.multiprocessing as mp
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=200) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(r['n_local_edges'] for r in results.values()) == _graph()[1].size(1)
+    assert all(r['n_local_edges'] > 0 for r in results.values())
+    print('edge-shard results', results)
+    for rank, r in results.items():
+        assert r['y'] < 1e-5, (rank, r)
+        assert r['gx_edges'] < 2e-5 and r['gx_nodes'] < 2e-5 and r['gp'] < 2e-5, (rank, r)
