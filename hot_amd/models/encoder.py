@@ -1,13 +1,14 @@
 """Encoder / EncLayer assembly (hot_pytorch/models/encoder.py:20-96) for the sparse kernel-attention path.
 
-Supported here: sparse=True with att_cfg in {'kernel', 'generalized_kernel'} and output order > 0.  The dense
-layout and the quadratic softmax attention (att_cfg='default', and the order-0 readout layer that always uses
-it) are outside the hot path built so far and raise NotImplementedError."""
+Supported here: sparse=True with att_cfg in {'kernel', 'generalized_kernel'}; an order-0 output layer uses the
+softmax readout SelfAttn(·, 0) exactly as the reference does (encoder.py:34-35), which is linear in |E|.  The dense
+layout and the quadratic softmax attention for output orders >= 1 (att_cfg='default') raise NotImplementedError."""
 from typing import Union
 
 import torch.nn as nn
 
 from .sparse.kernelattn import KernelSelfAttn
+from .sparse.attn import SelfAttn
 from .sparse.f import Apply, Add
 from .sparse.linear import Linear
 from ..batch.sparse import Batch as S
@@ -22,14 +23,17 @@ class EncLayer(nn.Module):
         assert att_cfg in ('default', 'kernel', 'generalized_kernel')
         if not sparse:
             raise NotImplementedError('hot_amd implements the sparse layout only')
-        if att_cfg == 'default' or ord_out == 0:
-            raise NotImplementedError('softmax SelfAttn (att_cfg="default" / order-0 readout) is not part of the '
-                                      'kernel-attention hot path built so far')
+        if att_cfg == 'default' and ord_out != 0:
+            raise NotImplementedError('softmax SelfAttn with an order >= 1 output is quadratic in |E| and not part of '
+                                      'the linear-cost path (use att_cfg="kernel" / "generalized_kernel")')
         self.add = Add()
         self.sparse = sparse
         self.ln = Apply(nn.LayerNorm(dim_in))
         # (dim_qk, dim_v) land in KernelSelfAttn's (dim_v, dim_qk) slots, exactly as in the reference (encoder.py:37)
-        self.attn = KernelSelfAttn(ord_in, ord_out, dim_in, dim_qk, dim_v, n_heads, cfg, dropout, drop_mu, feature_map)
+        if ord_out == 0:
+            self.attn = SelfAttn(ord_in, ord_out, dim_in, dim_qk, dim_v, n_heads, cfg, dropout, drop_mu)
+        else:
+            self.attn = KernelSelfAttn(ord_in, ord_out, dim_in, dim_qk, dim_v, n_heads, cfg, dropout, drop_mu, feature_map)
         self.residual = False
         self.ffn = nn.Sequential(
             Apply(nn.LayerNorm(dim_in)),

@@ -1,5 +1,6 @@
 from .linear import Linear  # noqa: F401
 from .kernelattncoef import KernelFeatureMapWrapper, KernelAttnCoef  # noqa: F401
 from .kernelattn import KernelSelfAttn  # noqa: F401
+from .attn import SelfAttn  # noqa: F401
 from .f import Apply, Nonlinear, Add  # noqa: F401
 from .readout import SumPool, AvgPool  # noqa: F401

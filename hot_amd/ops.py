@@ -408,6 +408,40 @@ class KernelAttn(Function):
         return dq.view(q.shape), dk.view(k.shape), dv.view(ctx.vshape), None, None, None, None, None, None
 
 
+class SoftmaxPool(Function):
+    """Per-graph softmax attention with a zeroth-order query: out[b] = sum_r softmax_r(q_b . k_r / sqrt(d)) v_r over the
+    kept rows of graph b, per head.  Stands in for AttnCoef._vector_query + apply_attn(k = 0)
+    (models/sparse/attncoef.py:25-59,165-173)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, seg, kind, keep, H):
+        beg, end, _, _ = seg
+        qs, ldq, nb, Cq = rows2d(q)
+        ks, ldk, n, Ck = rows2d(k)
+        vs, ldv, nv, Cv = rows2d(v)
+        assert Cq == Ck and nv == n and nb == beg.numel() and Cq % H == 0 and Cv % H == 0 and kind.numel() == n
+        d, c = Cq // H, Cv // H
+        out = torch.empty(nb, Cv, dtype=q.dtype, device=q.device)
+        alpha = torch.zeros(n, H, dtype=q.dtype, device=q.device)
+        call('hotk_seg_softmax_pool_fwd', 4 * n * (Ck + Cv), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end), p(kind),
+             keep, p(out), Cv, p(alpha), nb, H, d, c)
+        ctx.save_for_backward(qs, ks, vs, alpha, out, beg, end)
+        ctx.cfg = (ldq, ldk, ldv, nb, n, H, d, c, q.shape, k.shape, v.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qs, ks, vs, alpha, out, beg, end = ctx.saved_tensors
+        ldq, ldk, ldv, nb, n, H, d, c, qshape, kshape, vshape = ctx.cfg
+        g = g.contiguous()
+        dq = torch.zeros(nb, H * d, dtype=g.dtype, device=g.device)
+        dk = torch.zeros(n, H * d, dtype=g.dtype, device=g.device)
+        dv = torch.zeros(n, H * c, dtype=g.dtype, device=g.device)
+        call('hotk_seg_softmax_pool_bwd', 4 * n * 2 * H * (d + c), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end),
+             p(alpha), p(out), H * c, p(g), H * c, p(dq), H * d, p(dk), H * d, p(dv), H * c, nb, H, d, c)
+        return dq.view(qshape), dk.view(kshape), dv.view(vshape), None, None, None, None
+
+
 def _ptr(t):
     return 0 if t is None else t.data_ptr()
 

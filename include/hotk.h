@@ -179,6 +179,23 @@ int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const
                     float* out, int64_t ld_out, int64_t n, int HH, int m, int c, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Order-0 softmax readout: segmented softmax pooling with a per-segment (per-graph) query vector
+ * (models/sparse/attncoef.py:25-59 `_vector_query`, apply_attn with a zeroth-order query :165-173; callers
+ * SelfAttn._1_to_0 / _2_to_0, models/sparse/attn.py:82-131).
+ *   s[r][h] = q[b][h*d..] . k[r][h*d..] / sqrt(d) over the rows r of segment b whose kind is in `keep`;
+ *   alpha = softmax over those rows (0 elsewhere, all 0 for an empty set); out[b][h*c+ch] = sum_r alpha[r][h] v[r][h*c+ch].
+ * alpha [n_rows, H] is written for the rows inside segments (caller zero-fills) and feeds the backward pass, which
+ * writes dq [n_seg, H*d] and the kept rows of dk / dv (caller zero-fills those too).
+ * ---------------------------------------------------------------------------------------------- */
+int hotk_seg_softmax_pool_fwd(const float* q, int64_t ld_q, const float* k, int64_t ld_k, const float* v, int64_t ld_v,
+                              const int32_t* seg_begin, const int32_t* seg_end, const uint8_t* kind, unsigned keep,
+                              float* out, int64_t ld_out, float* alpha, int64_t n_seg, int H, int d, int c, void* stream);
+int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int64_t ld_k, const float* v, int64_t ld_v,
+                              const int32_t* seg_begin, const int32_t* seg_end, const float* alpha, const float* out,
+                              int64_t ld_out, const float* dout, int64_t ld_dout, float* dq, int64_t ld_dq, float* dk,
+                              int64_t ld_dk, float* dv, int64_t ld_dv, int64_t n_seg, int H, int d, int c, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Fused attention core of KernelSelfAttn(2,2) (models/sparse/kernelattn.py:119-159): all ten kernel-attention
  * terms from the raw projections, for the shape 4 heads x 16 features (one wavefront per slot), head width 8,
  * value width 8, generalized (ReLU) feature map.  Other shapes: HOTK_EUNSUPPORTED (use the general kernels).

@@ -20,7 +20,8 @@ from hot_pytorch.models.common.kernel import KernelFeatureMap  # noqa: E402
 from hot_pytorch.models.sparse.kernelattncoef import KernelFeatureMapWrapper, KernelAttnCoef  # noqa: E402
 from hot_pytorch.models.sparse.kernelattn import KernelSelfAttn  # noqa: E402
 from hot_pytorch.models.sparse.linear import Linear  # noqa: E402
-from hot_pytorch.models.encoder import EncLayer  # noqa: E402
+from hot_pytorch.models.encoder import EncLayer, Encoder  # noqa: E402
+from hot_pytorch.models.sparse.attn import SelfAttn  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -219,8 +220,58 @@ def dump_layer(name, nf, ei, ef, dim_qk, dim_v, n_heads, seed):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def dump_readout(name, nf, ei, ef, dim_qk, dim_v, n_heads, seed):
+    """F8: the linear-cost softmax readouts SelfAttn(2,0) / SelfAttn(1,0) (sparse/attn.py:82-131, attncoef.py:25-59)
+    and a whole Encoder(2, 0, [2], ...) with the generalized kernel (8f-1), fixed projections."""
+    torch.manual_seed(seed)
+    G = make_batch(nf, ei, ef)
+    D = G.values.size(-1)
+    out = pack_inputs(nf, ei, ef)
+    out['dims'] = np.array([D, dim_v, dim_qk, n_heads])
+    for oi in (2, 1):
+        tag = f'r{oi}0'
+        layer = SelfAttn(oi, 0, D, dim_v, dim_qk, n_heads, 'default', 0., 0.)
+        for n_, p in layer.named_parameters():
+            if 'bias' in n_:
+                torch.nn.init.normal_(p, std=0.1)
+        x = G.values.clone().requires_grad_(True)
+        Gin = batch_like(G, x, skip_masking=True)
+        if oi == 1:
+            Gin = d(Gin)
+        y = layer(Gin)
+        R = torch.randn_like(y)
+        (y * R).sum().backward()
+        for k, v in layer.state_dict().items():
+            out[f'{tag}/sd/{k}'] = npy(v)
+        for k, p in layer.named_parameters():
+            out[f'{tag}/grad/{k}'] = npy(p.grad)
+        out[f'{tag}/y'] = npy(y); out[f'{tag}/R'] = npy(R); out[f'{tag}/gx'] = npy(x.grad)
+    dh, dout = 16, 3
+    out['enc_dims'] = np.array([D, dout, dh, dim_qk, dim_v, 2 * dh, n_heads, dim_qk, dim_v, n_heads])
+    enc = Encoder(2, 0, [2], D, dout, dh, dim_qk, dim_v, 2 * dh, n_heads, dim_qk, dim_v, n_heads, 'default',
+                  'generalized_kernel', 0., 0., 0., sparse=True)
+    enc.skip_redraw_projections = True
+    for n_, p in enc.named_parameters():
+        if 'bias' in n_ and p.dim() == 1:
+            torch.nn.init.normal_(p, std=0.1)
+    x = G.values.clone().requires_grad_(True)
+    y = enc(batch_like(G, x, skip_masking=True))
+    R = torch.randn_like(y)
+    (y * R).sum().backward()
+    for k, v in enc.state_dict().items():
+        out[f'enc0/sd/{k}'] = npy(v)
+    for k, p in enc.named_parameters():
+        out[f'enc0/grad/{k}'] = npy(p.grad)
+    out['enc0/y'] = npy(y); out['enc0/R'] = npy(R); out['enc0/gx'] = npy(x.grad)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'readout':     # later additions are generated alone: earlier files stay as committed
+        dump_readout('readout_small.npz', *rand_graphs([5, 3, 6, 1, 4], 0.5, 4, 4, seed=51), dim_qk=8, dim_v=8, n_heads=2, seed=52)
+        dump_readout('readout_c2.npz', *rand_graphs([14, 9, 20], 0.15, 16, 16, seed=53, symmetric=True), dim_qk=32, dim_v=32, n_heads=4, seed=54)
+        return
     # F1/F2 index utilities
     dump_util('util_reftest.npz', *ref_tests_transpose_fixture())
     dump_util('util_random.npz', *rand_graphs([5, 1, 7, 3, 4, 6], 0.4, 3, 2, seed=11))

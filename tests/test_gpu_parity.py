@@ -198,6 +198,52 @@ def test_kernel_self_attn_layer_vs_reference(name):
         assert rel_err(p_.grad.cpu(), z[f'enc/grad/{k}']) < 2 * TOL, k
 
 
+def _check_param_grads(module, z, prefix):
+    """A softmax is invariant to a shift of its logits, so the key biases in front of it have an exactly zero
+    gradient that both sides compute as rounding noise (1e-9): errors are measured against the larger of the
+    parameter's own gradient scale and 1e-3 of the largest gradient in the module."""
+    scale = max(float(np.abs(z[prefix + k]).max()) for k, _ in module.named_parameters())
+    for k, p_ in module.named_parameters():
+        ref = tt(z[prefix + k])
+        err = float((p_.grad.cpu() - ref).abs().max())
+        assert err < 2 * TOL * max(float(ref.abs().max()), 1e-3 * scale), (prefix, k, err)
+
+
+@pytest.mark.parametrize('name', ['readout_small.npz', 'readout_c2.npz'])
+def test_softmax_readout_and_encoder_vs_reference(name):
+    """Order-0 softmax readouts SelfAttn(2,0) / SelfAttn(1,0) (segmented softmax-pooling kernel) and a whole
+    Encoder(2, 0, [2], ...) = input Linear + kernel EncLayer(2,2) + readout EncLayer(2,0) + output head, against the
+    reference's outputs and gradients (8f-1; one graph of the small fixture has a single node and no edge: empty
+    softmax set)."""
+    from hot_amd.models.encoder import Encoder
+    _, _, _, bs, KernelFeatureMap, ms, EncLayer = _product()
+    z = load_golden(name)
+    G0 = gpu_batch(z)
+    D, dim_v, dim_qk, H = [int(x) for x in z['dims']]
+    for oi in (2, 1):
+        tag = f'r{oi}0'
+        layer = _load_layer(ms.SelfAttn(oi, 0, D, dim_v, dim_qk, H, 'default', 0., 0.), z, tag)
+        x = G0.values.clone().requires_grad_(True)
+        G = bs.batch_like(G0, x, skip_masking=True)
+        if oi == 1:
+            G = bs.d(G)
+        y = layer(G)
+        assert rel_err(y.detach().cpu(), z[f'{tag}/y']) < TOL, tag
+        (y * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
+        assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
+        _check_param_grads(layer, z, f'{tag}/grad/')
+    D, dout, dh, dqk, dv, dff, nh, rq, rv, rh = [int(x) for x in z['enc_dims']]
+    enc = Encoder(2, 0, [2], D, dout, dh, dqk, dv, dff, nh, rq, rv, rh, 'default', 'generalized_kernel', 0., 0., 0., sparse=True)
+    enc = _load_layer(enc, z, 'enc0')
+    enc.skip_redraw_projections = True
+    x = G0.values.clone().requires_grad_(True)
+    y = enc(bs.batch_like(G0, x, skip_masking=True))
+    assert rel_err(y.detach().cpu(), z['enc0/y']) < TOL
+    (y * tt(z['enc0/R']).to(DEV)).sum().backward()
+    assert rel_err(x.grad.cpu(), z['enc0/gx']) < 2 * TOL
+    _check_param_grads(enc, z, 'enc0/grad/')
+
+
 def _ba_case(n_graphs, seed):
     from oracle import hot_oracle as O
     rng = np.random.default_rng(seed)
