@@ -276,6 +276,21 @@ __device__ __forceinline__ void pipeline4(int cnt, LoadF load, UseF use) {
   }
 }
 
+// depth-2 variant for register-heavy consumers
+template <int NR, class LoadF, class UseF>
+__device__ __forceinline__ void pipeline2(int cnt, LoadF load, UseF use) {
+  if (cnt <= 0) return;
+  const int last = cnt - 1;
+  float r0[NR], r1[NR];
+  load(0, r0);
+  for (int k = 0; k < cnt; k += 2) {
+    load(k + 1 < last ? k + 1 : last, r1);
+    use(k, r0);
+    load(k + 2 < last ? k + 2 : last, r0);
+    if (k + 1 < cnt) use(k + 1, r1);
+  }
+}
+
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
 
 // per-graph sums <-> memory: slot base = [KVG_C][64] floats, channels 0..8 F layout, 9..24 rotated
@@ -665,21 +680,23 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
   pipeline4<3>((int)(rb - ra), load, use);
 }
 
-// wave per chunk of 16 consecutive rows of one graph
-__global__ __launch_bounds__(TPB, 3) void k_graphsum_bwd(A a) {
+// wave per chunk of 16 consecutive rows of one kind of one graph; one instantiation per kind, so that only that kind's
+// two dKVg slots (F layout + rotated) are live
+template <bool DIAG>
+__global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
-  const int64_t cpg = (a.Emax + GB_ROWS - 1) / GB_ROWS;
+  const int64_t span = DIAG ? a.Nmax : a.Emax;
+  const int64_t cpg = (span + GB_ROWS - 1) / GB_ROWS;
   const int64_t nwork = a.B * cpg;
   for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
-    int64_t b, r0, r1;
-    chunk_rows(a, w, (int)cpg, GB_ROWS, &b, &r0, &r1);
-    if (r1 <= r0) continue;
-    const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
-    const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
-    graphsum_bwd_rows<true>(L, a, stage, b, r0, rm);
-    graphsum_bwd_rows<false>(L, a, stage, b, rm, r1);
+    const int64_t b = w / cpg, k = w - b * cpg;
+    const int64_t nn = a.n_nodes[b];
+    const int64_t lo = b * a.Emax + (DIAG ? 0 : nn), hi = b * a.Emax + (DIAG ? nn : (int64_t)a.n_entries[b]);
+    const int64_t r0 = lo + k * GB_ROWS;
+    const int64_t r1 = r0 + GB_ROWS < hi ? r0 + GB_ROWS : hi;
+    graphsum_bwd_rows<DIAG>(L, a, stage, b, r0, r1);
   }
 }
 
@@ -855,7 +872,8 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   float* part = (float*)workspace;
   hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
   hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4, 1, 256 * 16)), dim3(256), 0, st, part, a->dkvg, a->B, cpg, 1);
-  hipLaunchKernelGGL(k_graphsum_bwd, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_graphsum_bwd<true>, dim3(hotk_grid(a->B * ((a->Nmax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL(k_graphsum_bwd<false>, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(TPB), 0, st, *a);

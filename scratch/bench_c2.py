@@ -1,0 +1,41 @@
+"""scratch: C2-shaped step: enc-small Encoder on PCQM-like synthetic molecules, fwd + L1 loss backward."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hot_amd.batch.sparse import make_batch_concatenated
+from hot_amd.models.encoder import Encoder
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+dev = 'cuda'
+rng = np.random.default_rng(0)
+nn_, ne_, eis = [], [], []
+for _ in range(B):
+    n = int(rng.integers(8, 21))
+    m = int(round(1.05 * n))
+    und = set()
+    while len(und) < m:
+        i, j = rng.integers(0, n, 2)
+        if i != j:
+            und.add((min(i, j), max(i, j)))
+    e = sorted([(i, j) for i, j in und] + [(j, i) for i, j in und])
+    eis.append(np.array(e, dtype=np.int64).T); nn_.append(n); ne_.append(len(e))
+ei = torch.from_numpy(np.concatenate(eis, axis=1)).to(dev)
+nf = torch.randn(sum(nn_), 256, device=dev); ef = torch.randn(sum(ne_), 256, device=dev)
+G = make_batch_concatenated(nf, ei, ef, nn_, ne_)
+torch.manual_seed(0)
+enc = Encoder(2, 0, [2] * 8, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel', 0., 0., 0., sparse=True).to(dev)
+enc.skip_redraw_projections = True
+head = torch.nn.Linear(256, 1).to(dev)
+params = list(enc.parameters()) + list(head.parameters())
+print('graphs', B, 'entries', sum(G.n_edges), 'padded', G.values.shape[0] * G.values.shape[1], 'params %.2f M' % (sum(p.numel() for p in params) / 1e6))
+def step():
+    y = head(enc(G)).squeeze(-1)
+    loss = torch.nn.functional.l1_loss(y, torch.zeros_like(y))
+    loss.backward()
+    for p in params: p.grad = None
+for _ in range(3): step()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+K = 10
+for _ in range(K): step()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / K
+print('step %.2f ms  -> %.3e entries/s' % (dt * 1e3, sum(G.n_edges) / dt))
