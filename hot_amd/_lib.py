@@ -56,6 +56,7 @@ class Attn22Args(ctypes.Structure):
                 [(n, _P) for n in ('kind', 'nkind', 'rown', 'coln', 'tpos', 'diag_pos', 'col_ptr', 'col_perm',
                                    'row_ptr', 'row_perm', 'n_entries', 'n_nodes', 'col_rec', 'row_rec')] +
                 [('h1', _P), ('ld_h1', _L), ('h2', _P), ('ld_h2', _L), ('v', _P), ('ld_v', _L), ('proj', _P),
+                 ('phik', _P), ('ld_phik', _L),
                  ('att', _P), ('ld_att', _L), ('kvg', _P),
                  ('datt', _P), ('ld_datt', _L), ('dout', _P), ('ld_dout', _L),
                  ('dh1', _P), ('ld_dh1', _L), ('dh2', _P), ('ld_dh2', _L), ('dv', _P), ('ld_dv', _L),

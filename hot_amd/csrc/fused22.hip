@@ -249,6 +249,19 @@ __device__ __forceinline__ void kv_bwd(const LaneB& L, const float (&k)[DH], con
   if (L.x < DH) dk[L.h * DH + L.x] = d;
 }
 
+// the same for a key whose feature phi comes from the per-node table (pre > 0  <=>  phi > eps)
+__device__ __forceinline__ void kv_bwd_phi(const LaneB& L, float phi, const float (&val)[NC], const float (&dkv)[NC + 1],
+                                           const float (&drot)[NM], float* __restrict__ dv, float* __restrict__ dk) {
+  float dphi = dkv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
+  const float dvv = rot_dot(phi, drot);
+  if (dv && L.x < NC) dv[L.h * NC + L.x] = dvv;
+  const float dpre = phi > PHI_EPS ? dphi : 0.f;
+  const float d = rot_dot(dpre, L.pr);
+  if (L.x < DH) dk[L.h * DH + L.x] = d;
+}
+
 __device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
   for (int i = L.lane; i < nslots * SLOT; i += 64) p[i] = 0.f;
 }
@@ -344,32 +357,45 @@ __device__ __forceinline__ void chunk_rows(const A& a, int64_t w, int cpg, int r
   *r1 = e < rend ? e : rend;
 }
 
-// rows [ra, rb) of graph b, all diagonal (DIAG) or all off-diagonal: two coalesced loads per row
+// rows [ra, rb) of graph b, all diagonal (DIAG) or all off-diagonal.  Diagonal rows take phi(key) from the per-node
+// table (slots 6, 7), off-diagonal rows compute it from the raw entry-level key.
 template <bool DIAG>
 __device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* stage, int64_t b, int64_t ra, int64_t rb,
                                               float (&kv)[4][NC + 1]) {
   const bool lo = L.lane < 32;
-  auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
+  auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
     const float* vr = a.v + row * a.ld_v;
     if (DIAG) {
       const int64_t n = b * a.Nmax + (row - b * a.Emax);
-      r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
-      r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];          // slot 6 | slot 8
+      r[0] = a.phik[n * a.ld_phik + 6 * 64 + L.lane];
+      r[1] = a.phik[n * a.ld_phik + 7 * 64 + L.lane];
+      r[2] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];          // slot 6 | slot 8
     } else {
       r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
-      r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];          // slot 7 | slot 9
+      r[1] = 0.f;
+      r[2] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];          // slot 7 | slot 9
     }
   };
-  auto use = [&](int, const float (&r)[2]) __attribute__((always_inline)) {
-    stage_put<2>(L, stage, r);
+  auto use = [&](int, const float (&r)[3]) __attribute__((always_inline)) {
     float x[8], val[8];
-    slice8(L, stage, x); slice8(L, stage + 64, val);
-    kv_acc(kv[DIAG ? 0 : 1], phi_of(pre_x(L, x)), val);
-    slice8(L, stage + 32, x); slice8(L, stage + 96, val);
-    kv_acc(kv[DIAG ? 2 : 3], phi_of(pre_x(L, x)), val);
+    if (DIAG) {
+      const float rv[1] = {r[2]};
+      stage_put<1>(L, stage, rv);
+      slice8(L, stage, val);
+      kv_acc(kv[0], r[0], val);
+      slice8(L, stage + 32, val);
+      kv_acc(kv[2], r[1], val);
+    } else {
+      const float rv[2] = {r[0], r[2]};
+      stage_put<2>(L, stage, rv);
+      slice8(L, stage, x); slice8(L, stage + 64, val);
+      kv_acc(kv[1], phi_of(pre_x(L, x)), val);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, val);
+      kv_acc(kv[3], phi_of(pre_x(L, x)), val);
+    }
   };
-  pipeline4<2>((int)(rb - ra), load, use);
+  pipeline4<3>((int)(rb - ra), load, use);
 }
 
 __global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
@@ -435,45 +461,49 @@ __device__ __forceinline__ ColBlock col_block(const Lane& L, const A& a, int32_t
   return s;
 }
 
-// two coalesced loads for entry e = (i, j) of a column segment: key slots {2p, 2p+1} of node i and the value
-// slots {2p | 2p+1} where the transposed slot is read from row te
+// three coalesced loads for entry e = (i, j) of a column segment: phi of key slots {2p, 2p+1} of node i (per-node table,
+// F layout: the lane's own feature, no staging) and the value slots {2p | 2p+1}, the transposed one read from row te
 template <int P>
-__device__ __forceinline__ void load_kv2(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[2]) {
-  r[0] = a.h1[(int64_t)i * a.ld_h1 + (K1 + 2 * P) * SLOT + L.lane];
+__device__ __forceinline__ void load_kv3(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[3]) {
+  const float* pk = a.phik + (int64_t)i * a.ld_phik + 2 * P * 64 + L.lane;
+  r[0] = pk[0];
+  r[1] = pk[64];
   const bool lo = L.lane < 32;
   const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
   // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time:
   // selecting on the loaded value here would make the prefetch synchronous
-  r[1] = a.v[(int64_t)(row < 0 ? e : row) * a.ld_v + 2 * P * SLOT + L.lane];
+  r[2] = a.v[(int64_t)(row < 0 ? e : row) * a.ld_v + 2 * P * SLOT + L.lane];
 }
 
+// per_entry(e, te, phi0, phi1): the two value slices are staged at stage[0..32) and stage[32..64)
 template <int P, class F>
 __device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float* stage, int32_t n, F per_entry) {
   const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
   for (int32_t base = c0; base < c1; base += 64) {
     const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
     const ColBlock cb = col_block(L, a, base, cnt);
-    auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) { load_kv2<P>(L, a, rl(cb.e, k), rl(cb.i, k), rl(cb.te, k), r); };
-    auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
-      stage_put<2>(L, stage, r);
-      per_entry(rl(cb.e, k), rl(cb.te, k));
+    auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) { load_kv3<P>(L, a, rl(cb.e, k), rl(cb.i, k), rl(cb.te, k), r); };
+    auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
+      const float rv[1] = {r[2]};
+      stage_put<1>(L, stage, rv);
+      per_entry(rl(cb.e, k), rl(cb.te, k), r[0], r[1]);
     };
-    pipeline4<2>(cnt, load, use);
+    pipeline4<3>(cnt, load, use);
   }
 }
 
 template <int P>
 __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float* stage, int32_t n, float (&kv)[2][NC + 1]) {
   kv_zero<2>(kv);
-  for_col_entries<P>(L, a, stage, n, [&](int32_t, int32_t te) __attribute__((always_inline)) {
-    float x[8], val[8];
+  for_col_entries<P>(L, a, stage, n, [&](int32_t, int32_t te, float phi0, float phi1) __attribute__((always_inline)) {
+    float val[8];
     const float ts = te < 0 ? 0.f : 1.f;   // the transposed-value slot is slot 0 for P == 2, slot 1 otherwise
-    slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, val);
-    if (P == 2) kv_acc_scaled(kv[0], phi_of(pre_x(L, x)), val, ts);
-    else kv_acc(kv[0], phi_of(pre_x(L, x)), val);
-    slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
-    if (P == 2) kv_acc(kv[1], phi_of(pre_x(L, x)), val);
-    else kv_acc_scaled(kv[1], phi_of(pre_x(L, x)), val, ts);
+    slice8(L, stage + 0 * SLOT, val);
+    if (P == 2) kv_acc_scaled(kv[0], phi0, val, ts);
+    else kv_acc(kv[0], phi0, val);
+    slice8(L, stage + 1 * SLOT, val);
+    if (P == 2) kv_acc(kv[1], phi1, val);
+    else kv_acc_scaled(kv[1], phi1, val, ts);
   });
 }
 
@@ -639,34 +669,38 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), d1);
   kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), t0);
   kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), t1);
-  auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
+  auto load = [&](int k, float (&r)[4]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
     const float* vr = a.v + row * a.ld_v;
     if (DIAG) {
       const int64_t n = b * a.Nmax + (row - b * a.Emax);
-      r[0] = a.h1[n * a.ld_h1 + 10 * SLOT + L.lane];
+      r[0] = a.phik[n * a.ld_phik + 6 * 64 + L.lane];
+      r[3] = a.phik[n * a.ld_phik + 7 * 64 + L.lane];
       r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];
     } else {
       r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+      r[3] = 0.f;
       r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];
     }
     r[2] = (a.dout && L.lane < a.D) ? a.dout[row * a.ld_dout + L.lane] : 0.f;
   };
-  auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
+  auto use = [&](int k, const float (&r)[4]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
-    stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
     float* dvr = a.dv + row * a.ld_dv;
     float* dh2r = a.dh2 + row * a.ld_dh2;
     float x[8], val[8];
     if (DIAG) {
+      const float rv[1] = {r[1]};
+      stage_put<1>(L, stage, rv);
       float* dkn = a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 10 * SLOT;
-      slice8(L, stage, x); slice8(L, stage + 64, val);
-      kv_bwd(L, x, val, d0, t0, dvr + 6 * SLOT, dkn);
-      slice8(L, stage + 32, x); slice8(L, stage + 96, val);
-      kv_bwd(L, x, val, d1, t1, dvr + 8 * SLOT, dkn + SLOT);
+      slice8(L, stage, val);
+      kv_bwd_phi(L, r[0], val, d0, t0, dvr + 6 * SLOT, dkn);
+      slice8(L, stage + 32, val);
+      kv_bwd_phi(L, r[3], val, d1, t1, dvr + 8 * SLOT, dkn + SLOT);
       if (lo) { dvr[7 * SLOT + L.lane] = 0.f; dvr[9 * SLOT + L.lane] = 0.f; }
       zero_slots(L, dh2r, 8);   // entry-level queries / keys are masked on the diagonal
     } else {
+      stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
       slice8(L, stage, x); slice8(L, stage + 64, val);
       kv_bwd(L, x, val, d0, t0, dvr + 7 * SLOT, dh2r + K2 * SLOT);
       slice8(L, stage + 32, x); slice8(L, stage + 96, val);
@@ -677,7 +711,7 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
     if (L.lane < a.D) dh2r[8 * SLOT + L.lane] = r[2];
     for (int i = 64 + L.lane; i < a.D; i += 64) dh2r[8 * SLOT + i] = a.dout ? a.dout[row * a.ld_dout + i] : 0.f;
   };
-  pipeline4<3>((int)(rb - ra), load, use);
+  pipeline4<4>((int)(rb - ra), load, use);
 }
 
 // wave per chunk of 16 consecutive rows of one kind of one graph; one instantiation per kind, so that only that kind's
@@ -775,26 +809,26 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
     float drot0[NM], drot1[NM];
     kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
     kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
-    for_col_entries<P>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te) __attribute__((always_inline)) {
+    for_col_entries<P>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1) __attribute__((always_inline)) {
       float* dve = a.dv + (int64_t)e * a.ld_dv;
       float* dvt = te >= 0 ? a.dv + (int64_t)te * a.ld_dv : nullptr;
       float* ck = a.ck + (int64_t)e * (6 * SLOT) + 2 * P * SLOT;
       constexpr int S0 = 2 * P, S1 = 2 * P + 1;
       float* d0 = (P == 2) ? (dvt ? dvt + S0 * SLOT : nullptr) : dve + S0 * SLOT;
       float* d1 = (P == 2) ? dve + S1 * SLOT : (dvt ? dvt + S1 * SLOT : nullptr);
-      float x[8], val[8];
-      slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, val);
+      float val[8];
+      slice8(L, stage + 0 * SLOT, val);
       if (P == 2 && te < 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      kv_bwd(L, x, val, dkv[0], drot0, d0, ck);
-      slice8(L, stage + 1 * SLOT, x); slice8(L, stage + 3 * SLOT, val);
+      kv_bwd_phi(L, phi0, val, dkv[0], drot0, d0, ck);
+      slice8(L, stage + 1 * SLOT, val);
       if (P != 2 && te < 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      kv_bwd(L, x, val, dkv[1], drot1, d1, ck + SLOT);
+      kv_bwd_phi(L, phi1, val, dkv[1], drot1, d1, ck + SLOT);
       if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
     });
   }
@@ -804,6 +838,7 @@ int check_args(const A* a) {
   if (!a) return HOTK_EINVAL;
   if (a->H != NH || a->m != NM || a->d_head != DH || a->c != NC) return HOTK_EUNSUPPORTED;
   if (a->B < 0 || a->Emax < 0 || a->Nmax < 0 || a->R != a->B * a->Emax || a->Nn != a->B * a->Nmax) return HOTK_EINVAL;
+  if (!a->phik || a->ld_phik < 8 * 64) return HOTK_EINVAL;
   if (!a->h1 || !a->h2 || !a->v || !a->proj || !a->kind || !a->nkind || !a->rown || !a->coln || !a->tpos ||
       !a->diag_pos || !a->col_ptr || !a->col_perm || !a->row_ptr || !a->row_perm || !a->n_entries || !a->n_nodes || !a->col_rec || !a->row_rec)
     return HOTK_EINVAL;

@@ -518,6 +518,14 @@ class AttnCore22(Function):
         return a
 
     @staticmethod
+    def _phik(plan, h1, proj):
+        """phi of the eight node-level key slots, once per node (each node is the key of ~deg entries)"""
+        phik = torch.empty(plan.Nn, 512, dtype=torch.float32, device=h1.device)
+        call('hotk_phi_fwd', 4 * plan.Nn * (256 + 512), c_void_p_of(h1, 128), 384, p(proj), p(plan.nkind), KEEP_DIAG,
+             p(phik), 512, plan.Nn, 32, 8, 16, _lib.PHI_RELU, p(None))
+        return phik
+
+    @staticmethod
     def _workspace(plan, dev):
         need = c_size_t(0)
         check(lib().hotk_attn22_workspace_bytes(plan.B, plan.Emax, byref(need)), 'hotk_attn22_workspace_bytes')
@@ -536,6 +544,8 @@ class AttnCore22(Function):
         att = (torch.zeros if padded else torch.empty)(plan.R, 320, dtype=torch.float32, device=dev)
         kvg = torch.empty(plan.B, 4, 25, 64, dtype=torch.float32, device=dev)
         a = AttnCore22._args(plan, h1, h2, v, proj, D)
+        phik = AttnCore22._phik(plan, h1.view(plan.Nn, 384), proj)
+        a.phik, a.ld_phik = phik.data_ptr(), 512
         a.att, a.ld_att, a.kvg = att.data_ptr(), 320, kvg.data_ptr()
         ws, nws = AttnCore22._workspace(plan, dev)
         call('hotk_attn22_forward', 4 * plan.Ev * (8 * 32 + 10 * 32 + 10 * 32) + 4 * plan.Nn * 384,
@@ -544,13 +554,13 @@ class AttnCore22(Function):
         if padded:
             y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
         out = y.add_(h2.view(plan.R, -1)[:, 256:]).view(*h2.shape[:-1], D)
-        ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg)
+        ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg, phik)
         ctx.plan = plan
         return out
 
     @staticmethod
     def backward(ctx, d_out):
-        h1, h2, v, proj, w_o, att, kvg = ctx.saved_tensors
+        h1, h2, v, proj, w_o, att, kvg, phik = ctx.saved_tensors
         plan = ctx.plan
         dev = h2.device
         D = w_o.size(0)
@@ -569,6 +579,7 @@ class AttnCore22(Function):
         ck = torch.empty(plan.R, 192, dtype=torch.float32, device=dev)
         dkvg = torch.empty_like(kvg)
         a = AttnCore22._args(plan, h1, h2, v, proj, D)
+        a.phik, a.ld_phik = phik.data_ptr(), 512
         a.kvg = kvg.data_ptr()
         a.datt, a.ld_datt = datt.data_ptr(), 320
         a.dout, a.ld_dout = d_out.data_ptr(), D

@@ -202,6 +202,8 @@ int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int6
  *   h1  [Nn, >=12*32]  fc_1 output: raw query slots 0..3, raw key slots 4..11 (node level)
  *   h2  [R,  >= 8*32]  fc_2 output: raw query slots 0..5, raw key slots 6..7 (entry level), skip path after them
  *   v   [R,  >=10*32]  fc_v output (padding rows are ignored, they need not be zero)
+ *   phik[Nn, >= 8*64]  feature map of the eight node-level key slots, computed ONCE per node by hotk_phi_fwd
+ *                      (x = h1 + 4*32, HH = 32, d = 8, m = 16, ReLU): every node is the key of ~deg(i) entries
  *   att [R,  >=10*32]  the ten attention terms in the reference's concatenation order; valid rows are fully
  *                      written, padding rows are left untouched (caller zero-fills when the batch has padding)
  *   kvg [B,4,25,64]    per-graph sums (saved for the backward pass): per slot 9 feature-major channels + 16 rotated
@@ -222,6 +224,7 @@ typedef struct hotk_attn22_args {
   const float* h2; int64_t ld_h2;
   const float* v; int64_t ld_v;
   const float* proj;
+  const float* phik; int64_t ld_phik; /* [Nn, >= 8*64] phi of the node-level key slots (h1 slots 4..11), hotk_phi_fwd */
   float* att; int64_t ld_att;
   float* kvg;
   const float* datt; int64_t ld_datt;

@@ -25,6 +25,7 @@ dout = torch.randn(plan.R, 32, device=dev)
 dh1 = torch.empty(plan.Nn, 384, device=dev); dh2 = torch.empty(plan.R, 288, device=dev)
 dv = torch.empty(plan.R, 320, device=dev); ck = torch.empty(plan.R, 192, device=dev); dkvg = torch.empty_like(kvg)
 a = ops.AttnCore22._args(plan, h1, h2, v, proj, 32)
+phik = ops.AttnCore22._phik(plan, h1, proj); a.phik, a.ld_phik = phik.data_ptr(), 512
 a.att, a.ld_att, a.kvg = att.data_ptr(), 320, kvg.data_ptr()
 a.datt, a.ld_datt = datt.data_ptr(), 320
 a.dout, a.ld_dout = dout.data_ptr(), 32

@@ -14,6 +14,7 @@ h1 = torch.randn(plan.Nn, 384, device=dev); h2 = torch.randn(plan.R, 288, device
 proj = torch.randn(16, 8, device=dev); att = torch.empty(plan.R, 320, device=dev); kvg = torch.empty(plan.B, 4, 25, 64, device=dev)
 ck = torch.zeros(plan.R, 192, device=dev)
 a = ops.AttnCore22._args(plan, h1, h2, v, proj, 32)
+phik = ops.AttnCore22._phik(plan, h1, proj); a.phik, a.ld_phik = phik.data_ptr(), 512
 a.att, a.ld_att, a.kvg, a.ck = att.data_ptr(), 320, kvg.data_ptr(), ck.data_ptr()
 ws, nws = ops.AttnCore22._workspace(plan, dev)
 L = _lib.lib()

@@ -28,6 +28,7 @@ datt = torch.randn(plan.R, 320, device=dev); dout = torch.randn(plan.R, 32, devi
 dh1 = torch.empty(plan.Nn, 384, device=dev); dh2 = torch.empty(plan.R, 288, device=dev)
 dv = torch.empty(plan.R, 320, device=dev); ck = torch.empty(plan.R, 192, device=dev); dkvg = torch.empty_like(kvg)
 A = ops.AttnCore22._args(plan, h1, h2, v, proj, 32)
+phik = ops.AttnCore22._phik(plan, h1, proj); A.phik, A.ld_phik = phik.data_ptr(), 512
 A.att, A.ld_att, A.kvg = att.data_ptr(), 320, kvg.data_ptr()
 A.datt, A.ld_datt, A.dout, A.ld_dout = datt.data_ptr(), 320, dout.data_ptr(), 32
 A.dh1, A.ld_dh1, A.dh2, A.ld_dh2, A.dv, A.ld_dv = dh1.data_ptr(), 384, dh2.data_ptr(), 288, dv.data_ptr(), 320
