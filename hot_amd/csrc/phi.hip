@@ -47,6 +47,38 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd(const float* __res
   }
 }
 
+// d == 8, m == 16 (the C1 / C2 head shape), 16-byte aligned rows: a thread keeps its feature's projection row in
+// registers (256 threads = 16 whole heads, so the feature index of a thread never changes) and reads the 8-float head
+// slice as two 16-byte loads shared by the 16 threads of the head.  Same fmaf chain as proj_dot: identical bits.
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd_8x16(const float* __restrict__ x, int64_t ld_x,
+                                                                   const float* __restrict__ proj,
+                                                                   const uint8_t* __restrict__ kind, unsigned keep,
+                                                                   float* __restrict__ phi, int64_t ld_phi, int64_t n,
+                                                                   int HH, float scale, float eps) {
+  const int mm = threadIdx.x & 15;
+  float pr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pr[k] = proj[mm * 8 + k];
+  const int64_t F = (int64_t)HH * 16, total = n * F;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = t / F;
+    const int f = (int)(t - r * F);
+    const int hh = f >> 4;
+    float o = 0.f;
+    if (!kind || hotk_keep(keep, kind[r])) {
+      const float4 a = *reinterpret_cast<const float4*>(x + r * ld_x + hh * 8);
+      const float4 b = *reinterpret_cast<const float4*>(x + r * ld_x + hh * 8 + 4);
+      float s = 0.f;
+      s = fmaf(a.x * scale, pr[0], s); s = fmaf(a.y * scale, pr[1], s);
+      s = fmaf(a.z * scale, pr[2], s); s = fmaf(a.w * scale, pr[3], s);
+      s = fmaf(b.x * scale, pr[4], s); s = fmaf(b.y * scale, pr[5], s);
+      s = fmaf(b.z * scale, pr[6], s); s = fmaf(b.w * scale, pr[7], s);
+      o = fmaxf(s, 0.f) + eps;
+    }
+    phi[r * ld_phi + f] = o;
+  }
+}
+
 __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_bwd(const float* __restrict__ x, int64_t ld_x,
                                                               const float* __restrict__ proj,
                                                               const uint8_t* __restrict__ kind, unsigned keep,
@@ -290,7 +322,10 @@ extern "C" int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, con
   HOTK_CHECK_ARG(mode != HOTK_PHI_SOFTMAX_K || gstat);
   hipStream_t st = (hipStream_t)stream;
   const float scale = powf((float)d, -0.25f);
-  if (mode == HOTK_PHI_RELU) {
+  if (mode == HOTK_PHI_RELU && d == 8 && m == 16 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+    hipLaunchKernelGGL(k_phi_relu_fwd_8x16, dim3(hotk_grid(n * HH * m, PHI_THREADS, 256 * 32)), dim3(PHI_THREADS), 0, st, x,
+                       ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
+  } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_fwd, dim3(hotk_grid(n * HH * m, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, phi, ld_phi, n, HH, d, m, scale, 1e-3f);
   } else {

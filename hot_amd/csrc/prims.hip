@@ -64,10 +64,25 @@ __global__ void k_seg_sum_rows(const float* __restrict__ src, int64_t ld_src, co
     if (hi > e) hi = e;
     if (lo >= hi && ch > 0) continue;
     T acc = vzero(T());
-    for (int64_t p = lo; p < hi; ++p) {
-      int64_t r = perm ? (int64_t)perm[p] : p;
-      if (kind && !hotk_keep(keep, kind[r])) continue;
-      acc = vadd(acc, *reinterpret_cast<const T*>(src + r * ld_src + cv * V));
+    // four entries per step: index, kind and row loads of a step are independent of each other (one latency per
+    // step instead of three per entry); rows past the end re-read the last entry and are not added.  The additions
+    // stay in segment order, so the sum is bitwise the same as the one-at-a-time loop.
+    for (int64_t p = lo; p < hi; p += 4) {
+      int64_t r[4];
+      bool ok[4];
+      T v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t pp = p + u < hi ? p + u : hi - 1;
+        r[u] = perm ? (int64_t)perm[pp] : pp;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) ok[u] = (p + u < hi) && (!kind || hotk_keep(keep, kind[r[u]]));
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const T*>(src + r[u] * ld_src + cv * V);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) acc = vadd(acc, v[u]);
     }
     float* o = out + s * ld_out + cv * V;
     if (e - b <= HOTK_SEG_CHUNK) {
