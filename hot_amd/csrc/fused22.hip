@@ -305,6 +305,11 @@ __device__ __forceinline__ void pipeline2(int cnt, LoadF load, UseF use) {
 }
 
 __device__ __forceinline__ int rl(int v, int k) { return __builtin_amdgcn_readlane(v, k); }
+// element offset of row `row` (>= 0) for a leading dimension below 2^31 (checked on the host): a 32 x 32 -> 64 bit
+// product is two scalar instructions, the generic 64 x 64 one seven
+__device__ __forceinline__ int64_t rowoff(int32_t row, int64_t ld) {
+  return (int64_t)((uint64_t)(uint32_t)row * (uint64_t)(uint32_t)ld);
+}
 
 // per-graph sums <-> memory: slot base = [KVG_C][64] floats, channels 0..8 F layout, 9..24 rotated
 __device__ __forceinline__ const float* kvg_slot(const float* base, int64_t b, int s) {
@@ -337,6 +342,11 @@ constexpr int K1 = 4, K2 = 6;
 constexpr int STAGE_FLOATS = 6 * 64;
 constexpr int WPB = 1;            // waves per block: single-wave blocks release their slot as soon as the wave ends
 constexpr int TPB = 64 * WPB;
+// index of this wave in the grid, as a value the compiler knows to be wave-uniform (everything indexed by it --
+// segment pointers, node rows, graph ids -- then lives in scalar registers and is fetched by scalar loads)
+__device__ __forceinline__ int64_t wave_index() {
+  return (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6)));
+}
 #ifndef HOTK_GRID_CAP
 #define HOTK_GRID_CAP (1 << 20)
 #endif
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ d
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];   // rows below are the diagonal (layout invariant)
@@ -465,14 +475,14 @@ __device__ __forceinline__ ColBlock col_block(const Lane& L, const A& a, int32_t
 // F layout: the lane's own feature, no staging) and the value slots {2p | 2p+1}, the transposed one read from row te
 template <int P>
 __device__ __forceinline__ void load_kv3(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[3]) {
-  const float* pk = a.phik + (int64_t)i * a.ld_phik + 2 * P * 64 + L.lane;
+  const float* pk = a.phik + rowoff(i, a.ld_phik) + 2 * P * 64 + L.lane;
   r[0] = pk[0];
   r[1] = pk[64];
   const bool lo = L.lane < 32;
   const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
   // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time:
   // selecting on the loaded value here would make the prefetch synchronous
-  r[2] = a.v[(int64_t)(row < 0 ? e : row) * a.ld_v + 2 * P * SLOT + L.lane];
+  r[2] = a.v[rowoff(row < 0 ? e : row, a.ld_v) + 2 * P * SLOT + L.lane];
 }
 
 // per_entry(e, te, phi0, phi1): the two value slices are staged at stage[0..32) and stage[32..64)
@@ -514,7 +524,7 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   float* kvbuf = kvbuf_all[threadIdx.x >> 6];
-  for (int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float rot0[NM], rot1[NM];
     {
@@ -527,7 +537,7 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
       // node queries: terms 1, 2 (column sums) and 7, 8 (graph sums) go to the node's diagonal row
       const int64_t b = n / a.Nmax;
       const float* q = a.h1 + n * a.ld_h1;
-      float* o = a.att + (int64_t)a.diag_pos[n] * a.ld_att;
+      float* o = a.att + rowoff(a.diag_pos[n], a.ld_att);
       float r[2] = {q[L.lane], q[64 + L.lane]};
       float g0[NM], g1[NM];
       kvg_load_rot(L, kvg_slot(a.kvg, b, 0), g0);
@@ -551,13 +561,13 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
         const ColBlock cb = col_block(L, a, base, cnt);
         auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
-          const float* q = a.h2 + (int64_t)rl(cb.e, k) * a.ld_h2;
+          const float* q = a.h2 + rowoff(rl(cb.e, k), a.ld_h2);
           r[0] = q[L.lane];               // query slots 0, 1
           r[1] = q[4 * SLOT + L.lane];    // query slots 4, 5
         };
         auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
           if (rl(cb.kd, k) != 2) return;
-          float* o = a.att + (int64_t)rl(cb.e, k) * a.ld_att;
+          float* o = a.att + rowoff(rl(cb.e, k), a.ld_att);
           stage_put<2>(L, stage, r);
           float x[8];
           slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 2 * SLOT);
@@ -577,12 +587,12 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
         const int32_t rec = L.lane < cnt ? a.row_rec[base + L.lane] : -1;
         auto load = [&](int k, float (&r)[1]) __attribute__((always_inline)) {
           const int32_t e = rl(rec, k);
-          r[0] = a.h2[(int64_t)(e < 0 ? ~e : e) * a.ld_h2 + 2 * SLOT + L.lane];
+          r[0] = a.h2[rowoff(e < 0 ? ~e : e, a.ld_h2) + 2 * SLOT + L.lane];
         };
         auto use = [&](int k, const float (&r)[1]) __attribute__((always_inline)) {
           const int32_t e = rl(rec, k);
           if (e < 0) return;
-          float* o = a.att + (int64_t)e * a.ld_att;
+          float* o = a.att + rowoff(e, a.ld_att);
           stage_put<1>(L, stage, r);
           float x[8];
           slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 3 * SLOT);
@@ -646,7 +656,7 @@ __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict_
   const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
@@ -724,7 +734,7 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
   const int64_t span = DIAG ? a.Nmax : a.Emax;
   const int64_t cpg = (span + GB_ROWS - 1) / GB_ROWS;
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
     const int64_t b = w / cpg, k = w - b * cpg;
     const int64_t nn = a.n_nodes[b];
     const int64_t lo = b * a.Emax + (DIAG ? 0 : nn), hi = b * a.Emax + (DIAG ? nn : (int64_t)a.n_entries[b]);
@@ -745,7 +755,7 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
   float* stage = stage_all[threadIdx.x >> 6];
   float* kvbuf = kvbuf_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
-  for (int64_t n = (int64_t)blockIdx.x * WPB + (threadIdx.x >> 6); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float dkv[2][NC + 1];
     kv_zero<2>(dkv);
@@ -754,7 +764,7 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
       seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
       if (P == 0) {  // node queries (terms 1, 2)
         const int64_t dr = a.diag_pos[n];
-        float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[dr * a.ld_datt + L.lane]};
+        float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[rowoff((int32_t)dr, a.ld_datt) + L.lane]};
         float* dq = a.dh1 + n * a.ld_dh1;
         stage_put<2>(L, stage, r);
         float x[8], g[8];
@@ -767,12 +777,12 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
           const ColBlock cb = col_block(L, a, base, cnt);
           auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
             const int64_t e = rl(cb.e, k);
-            r[0] = a.h2[e * a.ld_h2 + L.lane];                                      // query slots 0, 1
-            r[1] = a.datt[e * a.ld_datt + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
+            r[0] = a.h2[rowoff((int32_t)e, a.ld_h2) + L.lane];                                      // query slots 0, 1
+            r[1] = a.datt[rowoff((int32_t)e, a.ld_datt) + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
           };
           auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
             if (rl(cb.kd, k) != 2) return;
-            float* dq = a.dh2 + (int64_t)rl(cb.e, k) * a.ld_dh2;
+            float* dq = a.dh2 + rowoff(rl(cb.e, k), a.ld_dh2);
             stage_put<2>(L, stage, r);
             float x[8], g[8];
             slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
@@ -788,13 +798,13 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
           auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
             const int32_t e_ = rl(rec, k);
             const int64_t e = e_ < 0 ? ~e_ : e_;
-            r[0] = a.h2[e * a.ld_h2 + 2 * SLOT + L.lane];                            // query slots 2, 3
-            r[1] = a.datt[e * a.ld_datt + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
+            r[0] = a.h2[rowoff((int32_t)e, a.ld_h2) + 2 * SLOT + L.lane];                            // query slots 2, 3
+            r[1] = a.datt[rowoff((int32_t)e, a.ld_datt) + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
           };
           auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
             const int32_t e = rl(rec, k);
             if (e < 0) return;
-            float* dq = a.dh2 + (int64_t)e * a.ld_dh2 + 2 * SLOT;
+            float* dq = a.dh2 + rowoff(e, a.ld_dh2) + 2 * SLOT;
             stage_put<2>(L, stage, r);
             float x[8], g[8];
             slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
@@ -810,9 +820,9 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
     kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
     kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
     for_col_entries<P>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1) __attribute__((always_inline)) {
-      float* dve = a.dv + (int64_t)e * a.ld_dv;
-      float* dvt = te >= 0 ? a.dv + (int64_t)te * a.ld_dv : nullptr;
-      float* ck = a.ck + (int64_t)e * (6 * SLOT) + 2 * P * SLOT;
+      float* dve = a.dv + rowoff(e, a.ld_dv);
+      float* dvt = te >= 0 ? a.dv + rowoff(te, a.ld_dv) : nullptr;
+      float* ck = a.ck + rowoff(e, 6 * SLOT) + 2 * P * SLOT;
       constexpr int S0 = 2 * P, S1 = 2 * P + 1;
       float* d0 = (P == 2) ? (dvt ? dvt + S0 * SLOT : nullptr) : dve + S0 * SLOT;
       float* d1 = (P == 2) ? dve + S1 * SLOT : (dvt ? dvt + S1 * SLOT : nullptr);
@@ -845,6 +855,10 @@ int check_args(const A* a) {
   if (a->ld_h1 < 12 * SLOT || a->ld_h2 < 8 * SLOT || a->ld_v < 10 * SLOT) return HOTK_EINVAL;
   // 16-byte vector loads of 8-float head slices
   if ((a->ld_h1 | a->ld_h2 | a->ld_v) & 3) return HOTK_EINVAL;
+  // row offsets are formed as 32 x 32 -> 64 bit products (rowoff)
+  if (a->R > INT32_MAX || a->Nn > INT32_MAX) return HOTK_EUNSUPPORTED;
+  for (int64_t ld : {a->ld_h1, a->ld_h2, a->ld_v, a->ld_phik, a->ld_att, a->ld_datt, a->ld_dout, a->ld_dh1, a->ld_dh2, a->ld_dv})
+    if (ld < 0 || ld > INT32_MAX) return HOTK_EINVAL;
   if (!hotk_aligned16(a->h1) || !hotk_aligned16(a->h2) || !hotk_aligned16(a->v)) return HOTK_EINVAL;
   return HOTK_OK;
 }
