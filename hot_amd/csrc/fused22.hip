@@ -70,27 +70,36 @@ HOTK_FMAC_ROR(2) HOTK_FMAC_ROR(3) HOTK_FMAC_ROR(4) HOTK_FMAC_ROR(5) HOTK_FMAC_RO
 HOTK_FMAC_ROR(9) HOTK_FMAC_ROR(10) HOTK_FMAC_ROR(11) HOTK_FMAC_ROR(12) HOTK_FMAC_ROR(13) HOTK_FMAC_ROR(14) HOTK_FMAC_ROR(15)
 #undef HOTK_FMAC_ROR
 
-// sum_k v[(x - k) & 15] * rot[k]: the 16-feature contraction of the C layout (two accumulation chains)
+// sum_k v[(x - k) & 15] * rot[k]: the 16-feature contraction of the C layout (two accumulation chains).  One asm
+// statement: between separate statements the compiler pads with s_nop (it cannot see that they carry no hazard),
+// which costs an issue slot per pair.  The plain multiply and one wait state separate a VALU write of v from the
+// first DPP read of it.
+#define HOTK_DPP_ROR(K) " row_ror:" #K " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 __device__ __forceinline__ float rot_dot(float v, const float (&rot)[NM]) {
-  float a0 = v * rot[0];
-  float a1;
-  asm volatile("s_nop 1\n\tv_mul_f32_dpp %0, %1, %2 row_ror:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-               : "=v"(a1) : "v"(v), "v"(rot[1]));
-  fmac_ror<2>(a0, v, rot[2]);
-  fmac_ror<3>(a1, v, rot[3]);
-  fmac_ror<4>(a0, v, rot[4]);
-  fmac_ror<5>(a1, v, rot[5]);
-  fmac_ror<6>(a0, v, rot[6]);
-  fmac_ror<7>(a1, v, rot[7]);
-  fmac_ror<8>(a0, v, rot[8]);
-  fmac_ror<9>(a1, v, rot[9]);
-  fmac_ror<10>(a0, v, rot[10]);
-  fmac_ror<11>(a1, v, rot[11]);
-  fmac_ror<12>(a0, v, rot[12]);
-  fmac_ror<13>(a1, v, rot[13]);
-  fmac_ror<14>(a0, v, rot[14]);
-  fmac_ror<15>(a1, v, rot[15]);
-  return a0 + a1;
+  float a0, a1;
+  asm volatile("v_mul_f32_e32 %0, %2, %3\n\t"
+               "s_nop 0\n\t"
+               "v_mul_f32_dpp %1, %2, %4" HOTK_DPP_ROR(1)
+               "v_fmac_f32_dpp %0, %2, %5" HOTK_DPP_ROR(2)
+               "v_fmac_f32_dpp %1, %2, %6" HOTK_DPP_ROR(3)
+               "v_fmac_f32_dpp %0, %2, %7" HOTK_DPP_ROR(4)
+               "v_fmac_f32_dpp %1, %2, %8" HOTK_DPP_ROR(5)
+               "v_fmac_f32_dpp %0, %2, %9" HOTK_DPP_ROR(6)
+               "v_fmac_f32_dpp %1, %2, %10" HOTK_DPP_ROR(7)
+               "v_fmac_f32_dpp %0, %2, %11" HOTK_DPP_ROR(8)
+               "v_fmac_f32_dpp %1, %2, %12" HOTK_DPP_ROR(9)
+               "v_fmac_f32_dpp %0, %2, %13" HOTK_DPP_ROR(10)
+               "v_fmac_f32_dpp %1, %2, %14" HOTK_DPP_ROR(11)
+               "v_fmac_f32_dpp %0, %2, %15" HOTK_DPP_ROR(12)
+               "v_fmac_f32_dpp %1, %2, %16" HOTK_DPP_ROR(13)
+               "v_fmac_f32_dpp %0, %2, %17" HOTK_DPP_ROR(14)
+               "v_fmac_f32_dpp %1, %2, %18" HOTK_DPP_ROR(15)
+               "v_add_f32_e32 %0, %0, %1"
+               : "=&v"(a0), "=&v"(a1)
+               : "v"(v), "v"(rot[0]), "v"(rot[1]), "v"(rot[2]), "v"(rot[3]), "v"(rot[4]), "v"(rot[5]), "v"(rot[6]),
+                 "v"(rot[7]), "v"(rot[8]), "v"(rot[9]), "v"(rot[10]), "v"(rot[11]), "v"(rot[12]), "v"(rot[13]),
+                 "v"(rot[14]), "v"(rot[15]));
+  return a0;
 }
 
 struct Lane {
@@ -202,8 +211,10 @@ __device__ __forceinline__ void apply_fwd(const Lane& L, const float (&q)[DH], c
                                           float* __restrict__ out) {
   const float phi = phi_of(pre_x(L, q));
   const float num = rot_dot(phi, rot);
-  float den = ror<8>(num);
-  if (den == 0.f) den = 1e-5f;
+  // The reference replaces a zero normaliser by 1e-5 (kernelattncoef.py:68-71).  phi > 0 and the key sums are >= 0,
+  // so the normaliser is zero only when the key set is empty, and then the numerator is zero as well: clamping from
+  // below gives the same quotient (0) with one instruction instead of a compare and a select.
+  const float den = fmaxf(ror<8>(num), 1e-30f);
   const float o = num * __builtin_amdgcn_rcpf(den);
   if (L.x < NC) out[L.h * NC + L.x] = o;
 }

@@ -266,8 +266,39 @@ def dump_readout(name, nf, ei, ef, dim_qk, dim_v, n_heads, seed):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def dump_mlp(name, nf, ei, ef, seed):
+    """F9: MLP stacks of Linear(cfg='default', normalize=True) (models/mlp.py:15-40, 8f-3): 2->2->2 (order-2 output),
+    2->2->1->0 (graph vector) and 2->1->1 (order-1 output); biases made non-zero so that they are pinned too."""
+    from hot_pytorch.models.mlp import MLP
+    torch.manual_seed(seed)
+    G = make_batch(nf, ei, ef)
+    D = G.values.size(-1)
+    out = pack_inputs(nf, ei, ef)
+    cases = {'m222': (2, 2, [2], D, 5, 7, 'relu'), 'm2210': (2, 0, [2, 1], D, 3, [6, 4], 'gelu'), 'm211': (2, 1, [1], D, 4, 5, 'tanh')}
+    for tag, (oi, oo, oh, di, do, dh, f) in cases.items():
+        mlp = MLP(oi, oo, oh, di, do, dh, f, 0., sparse=True)
+        for n_, p in mlp.named_parameters():
+            if 'bias' in n_:
+                torch.nn.init.normal_(p, std=0.1)
+        x = G.values.clone().requires_grad_(True)
+        y = mlp(batch_like(G, x, skip_masking=True))
+        yv = y if isinstance(y, torch.Tensor) else y.values
+        R = torch.randn_like(yv)
+        (yv * R).sum().backward()
+        for k, v in mlp.state_dict().items():
+            out[f'{tag}/sd/{k}'] = npy(v)
+        for k, p in mlp.named_parameters():
+            out[f'{tag}/grad/{k}'] = npy(p.grad)
+        out[f'{tag}/y'] = npy(yv); out[f'{tag}/R'] = npy(R); out[f'{tag}/gx'] = npy(x.grad)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'mlp':
+        dump_mlp('mlp_small.npz', *rand_graphs([5, 3, 6, 1, 4], 0.5, 3, 2, seed=61), seed=62)
+        dump_mlp('mlp_sym.npz', *rand_graphs([7, 4, 9], 0.35, 4, 4, seed=63, symmetric=True), seed=64)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'readout':     # later additions are generated alone: earlier files stay as committed
         dump_readout('readout_small.npz', *rand_graphs([5, 3, 6, 1, 4], 0.5, 4, 4, seed=51), dim_qk=8, dim_v=8, n_heads=2, seed=52)
         dump_readout('readout_c2.npz', *rand_graphs([14, 9, 20], 0.15, 16, 16, seed=53, symmetric=True), dim_qk=32, dim_v=32, n_heads=4, seed=54)

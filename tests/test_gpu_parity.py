@@ -244,6 +244,30 @@ def test_softmax_readout_and_encoder_vs_reference(name):
     _check_param_grads(enc, z, 'enc0/grad/')
 
 
+@pytest.mark.parametrize('name', ['mlp_small.npz', 'mlp_sym.npz'])
+def test_mlp_default_basis_vs_reference(name):
+    """MLP stacks of Linear(cfg='default', normalize=True) (models/mlp.py:15-40, 8f-3): order-2 output (15-op basis
+    twice), graph-vector output (2->2->1->0: 15-op, 5-op and pooling bases) and order-1 output, against the reference's
+    outputs and gradients; state_dict keys load unchanged."""
+    from hot_amd.models import MLP
+    _, _, _, bs, _, _, _ = _product()
+    z = load_golden(name)
+    G0 = gpu_batch(z)
+    D = G0.values.size(-1)
+    cases = {'m222': (2, 2, [2], D, 5, 7, 'relu'), 'm2210': (2, 0, [2, 1], D, 3, [6, 4], 'gelu'), 'm211': (2, 1, [1], D, 4, 5, 'tanh')}
+    for tag, (oi, oo, oh, di, do, dh, f) in cases.items():
+        mlp = _load_layer(MLP(oi, oo, oh, di, do, dh, f, 0., sparse=True), z, tag)
+        x = G0.values.clone().requires_grad_(True)
+        y = mlp(bs.batch_like(G0, x, skip_masking=True))
+        yv = y if isinstance(y, torch.Tensor) else y.values
+        assert rel_err(yv.detach().cpu(), z[f'{tag}/y']) < TOL, tag
+        (yv * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
+        assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
+        _check_param_grads(mlp, z, f'{tag}/grad/')
+    with pytest.raises(NotImplementedError):
+        MLP(2, 2, [2], D, 5, 7, sparse=False)
+
+
 def _ba_case(n_graphs, seed):
     from oracle import hot_oracle as O
     rng = np.random.default_rng(seed)
