@@ -1,0 +1,2 @@
+from .linear import Linear  # noqa: F401
+from .kernelattn import KernelSelfAttn  # noqa: F401

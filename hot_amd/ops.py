@@ -173,6 +173,28 @@ class GatherSeg(Function):
         return d.view(ctx.src_shape), None, None, None
 
 
+class GatherSum(Function):
+    """y[b] = sum_j P[idx_j[b], j*C:(j+1)*C] for the k index columns of a UniformPlan: the 1 -> k broadcast of the
+    uniform extension after the per-node products (models/uniform/linear.py:33-40, factored).  Backward of each
+    gather = segment sum over the hyperedges that hold the node in slot j."""
+
+    @staticmethod
+    def forward(ctx, P, plan, C):
+        assert P.size(-1) == plan.k * C
+        ctx.plan, ctx.C, ctx.N = plan, C, P.size(0)
+        y = None
+        for j in range(plan.k):
+            y = gather_rows(P[:, j * C:(j + 1) * C], plan.idx32[j], plan.B_rows, out=y, accumulate=j > 0)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, C = ctx.plan, ctx.C
+        g = g.contiguous()
+        dP = torch.cat([seg_sum_rows(g, plan.seg[j]) for j in range(plan.k)], dim=1)
+        return dP, None, None
+
+
 class Phi(Function):
     """Fused FAVOR+ feature map: head split -> projection -> ReLU/exp -> loop + padding masks.
     Stands in for KernelFeatureMapWrapper.forward (models/sparse/kernelattncoef.py:19-28) and

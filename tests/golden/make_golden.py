@@ -293,8 +293,52 @@ def dump_mlp(name, nf, ei, ef, seed):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def dump_uniform(name, N, B, k, D, dqk, dv, H, seed):
+    """F10: the 1 -> k-uniform extension (models/uniform/*, models/extension.py, 8f-2): Linear 1->1 / 1->k in both
+    cfgs, KernelSelfAttn 1->1 / 1->k with the generalized kernel, and a whole extension Encoder / MLP.  The GPS data of
+    k-uniform-hyperedge has 221 nodes and 3-node hyperedges; the fixture is a small synthetic set of that shape."""
+    from hot_pytorch.models.uniform.linear import Linear as ULinear
+    from hot_pytorch.models.uniform.kernelattn import KernelSelfAttn as UAttn
+    from hot_pytorch.models import extension as X
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    x0 = torch.randn(N, D, generator=g)
+    idx = torch.stack([torch.randperm(N, generator=g)[:k] for _ in range(B)])       # k distinct nodes per hyperedge
+    out = {'x': npy(x0), 'indices': idx.numpy(), 'dims': np.array([N, B, k, D, dqk, dv, H])}
+
+    def run(tag, mod, use_idx):
+        for n_, p in mod.named_parameters():
+            if 'bias' in n_ and p.dim() == 1:
+                torch.nn.init.normal_(p, std=0.1)
+        x = x0.clone().requires_grad_(True)
+        y = mod(x, idx) if use_idx else mod(x)
+        R = torch.randn(y.shape, generator=g)
+        (y * R).sum().backward()
+        for k_, v in mod.state_dict().items():
+            out[f'{tag}/sd/{k_}'] = npy(v)
+        for k_, p in mod.named_parameters():
+            out[f'{tag}/grad/{k_}'] = npy(p.grad)
+        gx = x.grad.to_dense() if x.grad.is_sparse else x.grad     # gather(sparse_grad=True) yields a sparse gradient
+        out[f'{tag}/y'] = npy(y); out[f'{tag}/R'] = npy(R); out[f'{tag}/gx'] = npy(gx)
+
+    for cfg in ('light', 'default'):
+        run(f'lin11_{cfg}', ULinear(1, 1, D, 5, cfg=cfg), False)
+        run(f'lin1k_{cfg}', ULinear(1, k, D, 6, cfg=cfg), True)
+    run('att11', UAttn(1, 1, D, dv, dqk, H, 'default', 0., 0., KernelFeatureMap(dqk // H, generalized_attention=True)), False)
+    run('att1k', UAttn(1, k, D, dv, dqk, H, 'default', 0., 0., KernelFeatureMap(dqk // H, generalized_attention=True)), True)
+    enc = X.Encoder(1, k, [1], D, 3, 16, dqk, dv, 32, H, dqk, dv, H, 'default', 'generalized_kernel', 0., 0., 0.)
+    enc.skip_redraw_projections = True
+    run('enc', enc, True)
+    run('mlp', X.MLP(1, k, [1], D, 4, 9, 'relu', 0.), True)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'uniform':
+        dump_uniform('uniform_small.npz', N=13, B=21, k=3, D=6, dqk=8, dv=8, H=2, seed=71)
+        dump_uniform('uniform_gps.npz', N=221, B=400, k=3, D=16, dqk=32, dv=32, H=4, seed=72)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'mlp':
         dump_mlp('mlp_small.npz', *rand_graphs([5, 3, 6, 1, 4], 0.5, 3, 2, seed=61), seed=62)
         dump_mlp('mlp_sym.npz', *rand_graphs([7, 4, 9], 0.35, 4, 4, seed=63, symmetric=True), seed=64)

@@ -268,6 +268,43 @@ def test_mlp_default_basis_vs_reference(name):
         MLP(2, 2, [2], D, 5, 7, sparse=False)
 
 
+@pytest.mark.parametrize('name', ['uniform_small.npz', 'uniform_gps.npz'])
+def test_uniform_extension_vs_reference(name):
+    """The 1 -> k-uniform extension (8f-2, config C4): uniform Linear 1->1 / 1->k (light, default), KernelSelfAttn
+    1->1 / 1->k with the generalized kernel, the extension Encoder and MLP, against the reference's outputs and
+    gradients; the reference's sparse gather gradient is compared densified."""
+    from hot_amd.models import extension as X
+    from hot_amd.models.uniform import Linear as ULinear, KernelSelfAttn as UAttn
+    _, _, _, _, KernelFeatureMap, _, _ = _product()
+    z = load_golden(name)
+    N, B, k, D, dqk, dv, H = [int(v) for v in z['dims']]
+    x0 = tt(z['x']).to(DEV)
+    idx = torch.from_numpy(z['indices']).to(DEV)
+
+    def run(tag, mod, use_idx):
+        mod = _load_layer(mod, z, tag)
+        x = x0.clone().requires_grad_(True)
+        y = mod(x, idx) if use_idx else mod(x)
+        assert rel_err(y.detach().cpu(), z[f'{tag}/y']) < TOL, tag
+        (y * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
+        assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
+        _check_param_grads(mod, z, f'{tag}/grad/')
+
+    for cfg in ('light', 'default'):
+        run(f'lin11_{cfg}', ULinear(1, 1, D, 5, cfg=cfg), False)
+        run(f'lin1k_{cfg}', ULinear(1, k, D, 6, cfg=cfg), True)
+    run('att11', UAttn(1, 1, D, dv, dqk, H, 'default', 0., 0., KernelFeatureMap(dqk // H, generalized_attention=True)), False)
+    run('att1k', UAttn(1, k, D, dv, dqk, H, 'default', 0., 0., KernelFeatureMap(dqk // H, generalized_attention=True)), True)
+    enc = X.Encoder(1, k, [1], D, 3, 16, dqk, dv, 32, H, dqk, dv, H, 'default', 'generalized_kernel', 0., 0., 0.)
+    enc.skip_redraw_projections = True
+    run('enc', enc, True)
+    run('mlp', X.MLP(1, k, [1], D, 4, 9, 'relu', 0.), True)
+    bad = idx.clone()
+    bad[0, 1] = bad[0, 0]
+    with pytest.raises(AssertionError):
+        enc(x0, bad)
+
+
 def _ba_case(n_graphs, seed):
     from oracle import hot_oracle as O
     rng = np.random.default_rng(seed)
