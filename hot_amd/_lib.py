@@ -35,6 +35,9 @@ _SIGNATURES = {
     'hotk_basis22_pair_fwd': [_P, _L, _P, _P, _P, _L, _L, _L, _P],
     'hotk_basis22_pair_bwd': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _L, _L, _P],
     'hotk_assemble22': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
+    'hotk_thin_gemm_supported': [_L, _L],
+    'hotk_thin_gemm_bias': [_P, _L, _P, _L, _L, _P, _P, _L, _P, _L, _L, _P],
+    'hotk_linear22_entry_fwd': [_P, _L, _P, _L, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_seg_softmax_pool_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _P, _U, _P, _L, _P, _L, _I, _I, _I, _P],
     'hotk_seg_softmax_pool_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
     'hotk_phi_fwd': [_P, _L, _P, _P, _U, _P, _L, _L, _I, _I, _I, _I, _P, _P],

@@ -1,0 +1,217 @@
+// Thin GEMMs of the layer with the weight resident in LDS and the row epilogue fused:  Y[R, C] = A[R, K] . W[K, C]
+// for R ~ 1e7 rows and K, C <= 320 (the dense projections fc_2 / fc_v / fc_o of models/sparse/kernelattn.py:46-51 and
+// their data gradients).  These products are streaming problems: 14 GB of rows move per call while the weight is
+// 40-74 KB, so the kernel keeps W in LDS for the life of a persistent workgroup, reads every A row once, feeds
+// v_mfma_f32_32x32x2_f32 (exact fp32, MI355X_MICROARCH.md: 256 FLOP/clk/CU) and applies the epilogue on the
+// accumulators before the only store:
+//   MODE 0: + bias[col] + res[row][col]                                       (nn.Linear forward / data gradient, skip path)
+//   MODE 1: the order-2 'light' assembly of models/sparse/linear.py:143-161,293-306,345-346 in factored form:
+//           off-diagonal (i,j): acc + yn[i][C..2C) + yn[j][2C..3C) + b_off;  diagonal (v,v): yn[v][0..C) + b_diag;
+//           padding: 0   (replaces a library GEMM followed by hotk_assemble22: one pass over Y instead of three)
+//
+// Work split: a workgroup of 4 waves takes 128 consecutive rows, a wave 32 of them, ONE ROW PER LANE PAIR: the MFMA
+// computes the transposed tile  Y^T[32 cols, 32 rows] = W^T . A^T, so lane (j = lane & 31, half = lane >> 5) supplies
+// A[row0 + j][half*K/2 + s] as the B operand (its K/2 values sit in registers, loaded as contiguous 16-byte pieces)
+// and one conflict-free ds_read_b32 of W as the A operand; MFMA step s contracts the K-pair {s, K/2 + s}.  In the C/D
+// map (col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); cdna_hip_programming.md, fragment layout)
+// a lane then owns, of ITS row, the four consecutive output columns 8 q + 4 half + (0..3) of every quad q = reg >> 2:
+// the epilogue is float4 loads / stores, the row's kind and node ids are read once per lane, and the gathered
+// addends of the next 32-column tile are requested before the current tile is finished (and before the next MFMA
+// loop), so their latency overlaps the matrix work.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Epi {
+  const float* bias;      // MODE 0: [C] or null
+  const float* res;       // MODE 0: residual rows [R, >= C] added to the result, or null
+  int64_t ld_res;
+  const float* yn;        // MODE 1: node table [Nn, 3C]
+  int64_t ld_yn;
+  const uint8_t* kind;    // MODE 1: row kinds
+  const int32_t* rown;
+  const int32_t* coln;
+  const float* b_off;     // MODE 1: [C] or null
+  const float* b_diag;
+};
+
+// addends of one 32-column tile for this lane's row: 4 quads x (first, second) float4
+struct Addend {
+  float4 u[4], w[4];
+};
+
+template <int MODE>
+__device__ __forceinline__ void fetch_addend(Addend& ad, const Epi& ep, const float* p1, const float* p2, const float* pres,
+                                             int col0) {
+  // col0 = n0 + 32 t + 4 half: the lane's first column of the tile; quad q adds 8 q
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    if (MODE == 1) {
+      ad.u[q] = *reinterpret_cast<const float4*>(p1 + col0 + 8 * q);
+      ad.w[q] = *reinterpret_cast<const float4*>(p2 + col0 + 8 * q);
+    } else if (pres) {
+      ad.u[q] = *reinterpret_cast<const float4*>(pres + col0 + 8 * q);
+    }
+  }
+}
+
+template <int KH, int TG, int MODE>
+__global__ __launch_bounds__(256) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                   float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
+  extern __shared__ __align__(16) float w_lds[];   // [2 KH][C]
+  constexpr int K = 2 * KH;
+  const int tid = threadIdx.x;
+  for (int i = tid * 4; i < K * C; i += 256 * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
+  __syncthreads();
+  const int wave = tid >> 6, lane = tid & 63, j = lane & 31, half = lane >> 5;
+  const int64_t n_tiles = (R + 127) / 128;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * 128 + wave * 32;
+    if (row0 >= R) continue;
+    const bool live = row0 + j < R;
+    const int64_t row = live ? row0 + j : R - 1;      // rows past the end re-read the last row and store nothing
+    // per-row epilogue operands: MODE 1 folds the three row kinds into two gathered rows, two multipliers and a bias
+    // selector (x2 is zero on diagonal and padding rows, so the accumulator contributes nothing there):
+    //   off-diagonal: acc + yn[i][C..) + yn[j][2C..) + b_off    diagonal: 0 + yn[v][0..) + 0 + b_diag    padding: 0
+    const float* p1 = nullptr;
+    const float* p2 = nullptr;
+    const float* pres = nullptr;
+    const float* pb = ep.bias;
+    float m1 = 0.f, m2 = 0.f, mb = pb ? 1.f : 0.f;
+    if (MODE == 1) {
+      const int kd = ep.kind[row];
+      // padding rows carry node id -1 (plan): they read node row 0 and multiply it by zero
+      const int32_t rn = ep.rown[row], cn = ep.coln[row];
+      const float* yi = ep.yn + (int64_t)(kd != 0 ? rn : 0) * ep.ld_yn;
+      const float* yj = ep.yn + (int64_t)(kd == 2 ? cn : 0) * ep.ld_yn;
+      p1 = kd == 2 ? yi + C : yi;
+      p2 = kd == 2 ? yj + 2 * C : yi;
+      m1 = kd != 0 ? 1.f : 0.f;
+      m2 = kd == 2 ? 1.f : 0.f;
+      pb = kd == 2 ? ep.b_off : ep.b_diag;
+      mb = (kd != 0 && pb) ? 1.f : 0.f;
+    } else if (ep.res) {
+      pres = ep.res + row * ep.ld_res;
+    }
+    if (!pb) pb = W;   // any readable address: multiplied by mb = 0
+    const float* ap = A + row * lda + half * KH;
+    float a[KH];
+#pragma unroll
+    for (int s = 0; s < KH; s += 4) {
+      const float4 t = *reinterpret_cast<const float4*>(ap + s);
+      a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
+    }
+    const float* wl = w_lds + half * KH * C + j;
+    float* yr = Y + row * ldy + 4 * half;
+    Addend cur, nxt;
+    fetch_addend<MODE>(cur, ep, p1, p2, pres, 4 * half);
+    for (int n0 = 0; n0 < C; n0 += 32 * TG) {
+      f32x16 acc[TG];
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+#pragma unroll
+      for (int s = 0; s < KH; ++s) {
+#pragma unroll
+        for (int t = 0; t < TG; ++t) {
+          const float b = wl[s * C + n0 + 32 * t];
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a[s], acc[t], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < TG; ++t) {
+        // request the next tile's addends (this group or the first tile of the next group) before finishing this one
+        const int ncol = (t + 1 < TG) ? n0 + 32 * (t + 1) : n0 + 32 * TG;
+        if (ncol < C) fetch_addend<MODE>(nxt, ep, p1, p2, pres, ncol + 4 * half);
+        const int col0 = n0 + 32 * t + 4 * half;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float4 bb = *reinterpret_cast<const float4*>(pb + col0 + 8 * q);
+          float4 v;
+          v.x = acc[t][4 * q + 0]; v.y = acc[t][4 * q + 1]; v.z = acc[t][4 * q + 2]; v.w = acc[t][4 * q + 3];
+          if (MODE == 1) {
+            v.x = fmaf(mb, bb.x, fmaf(m2, cur.w[q].x, fmaf(m1, cur.u[q].x, v.x)));
+            v.y = fmaf(mb, bb.y, fmaf(m2, cur.w[q].y, fmaf(m1, cur.u[q].y, v.y)));
+            v.z = fmaf(mb, bb.z, fmaf(m2, cur.w[q].z, fmaf(m1, cur.u[q].z, v.z)));
+            v.w = fmaf(mb, bb.w, fmaf(m2, cur.w[q].w, fmaf(m1, cur.u[q].w, v.w)));
+          } else {
+            v.x = fmaf(mb, bb.x, v.x); v.y = fmaf(mb, bb.y, v.y); v.z = fmaf(mb, bb.z, v.z); v.w = fmaf(mb, bb.w, v.w);
+            if (pres) { v.x += cur.u[q].x; v.y += cur.u[q].y; v.z += cur.u[q].z; v.w += cur.u[q].w; }
+          }
+          if (live) *reinterpret_cast<float4*>(yr + n0 + 32 * t + 8 * q) = v;
+        }
+        cur = nxt;
+      }
+    }
+  }
+}
+
+template <int KH, int TG, int MODE>
+int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
+           hipStream_t st) {
+  const size_t lds = (size_t)2 * KH * C * sizeof(float);
+  static bool attr_set = false;   // raising the dynamic-LDS limit of a kernel is a per-process property of the function
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess)
+      return HOTK_ELAUNCH;
+    attr_set = true;
+  }
+  const int64_t n_tiles = (R + 127) / 128;
+  // persistent workgroups: LDS (weight) allows two per CU at the C1 shapes
+  const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+  const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
+  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE>), dim3(grid), dim3(256), lds, st, A, lda, W, Y, ldy, R, C, ep);
+  return hotk_launch_status();
+}
+
+template <int MODE>
+int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, float* Y, int64_t ldy, int64_t R,
+             const Epi& ep, hipStream_t st) {
+  if (K == 64 && C % 96 == 0) return launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  if (K == 32 && C % 160 == 0) return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  if (K == 288 && C % 64 == 0) return launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  if (K == 320 && C % 32 == 0) return launch<160, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  return HOTK_EUNSUPPORTED;
+}
+
+bool shape_ok(int64_t K, int64_t C) {
+  const bool known = (K == 64 && C % 96 == 0) || (K == 32 && C % 160 == 0) || (K == 288 && C % 64 == 0) ||
+                     (K == 320 && C % 32 == 0);
+  return known && K * C * (int64_t)sizeof(float) <= 150 * 1024;
+}
+
+}  // namespace
+
+extern "C" int hotk_thin_gemm_supported(int64_t K, int64_t C) { return shape_ok(K, C) ? 1 : 0; }
+
+extern "C" int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
+                                   const float* res, int64_t ld_res, float* Y, int64_t ldy, int64_t R, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && K > 0 && C > 0 && lda >= K && ldy >= C && (!res || ld_res >= C));
+  if (!shape_ok(K, C)) return HOTK_EUNSUPPORTED;
+  if (R == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(A && W && Y && hotk_aligned16(A) && hotk_aligned16(W) && (lda & 3) == 0);
+  HOTK_CHECK_ARG(hotk_aligned16(Y) && (ldy & 3) == 0 && (!bias || hotk_aligned16(bias)) &&
+                 (!res || (hotk_aligned16(res) && (ld_res & 3) == 0)));
+  Epi ep{};
+  ep.bias = bias; ep.res = res; ep.ld_res = ld_res;
+  return dispatch<0>(A, lda, W, K, C, Y, ldy, R, ep, (hipStream_t)stream);
+}
+
+extern "C" int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
+                                       int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
+                                       const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R,
+                                       void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && K > 0 && C > 0 && ld_x2 >= K && ldy >= C && ld_yn >= 3 * C);
+  if (!shape_ok(K, C)) return HOTK_EUNSUPPORTED;
+  if (R == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(x2 && W && Y && yn && kind && rown && coln && hotk_aligned16(x2) && hotk_aligned16(W) && (ld_x2 & 3) == 0);
+  HOTK_CHECK_ARG(hotk_aligned16(Y) && (ldy & 3) == 0 && hotk_aligned16(yn) && (ld_yn & 3) == 0 && (C & 3) == 0 &&
+                 (!b_off || hotk_aligned16(b_off)) && (!b_diag || hotk_aligned16(b_diag)));
+  Epi ep{};
+  ep.yn = yn; ep.ld_yn = ld_yn; ep.kind = kind; ep.rown = rown; ep.coln = coln; ep.b_off = b_off; ep.b_diag = b_diag;
+  return dispatch<1>(x2, ld_x2, W, K, C, Y, ldy, R, ep, (hipStream_t)stream);
+}

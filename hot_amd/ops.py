@@ -96,6 +96,31 @@ def row_expand(KV, sidx, seg_div, X, xidx, XA, kind, keep, n, HH, m, c):
     return out
 
 
+THIN_MIN_ROWS = 1 << 15
+
+
+def thin_ok(R, K, C):
+    """the hand-written LDS-resident-weight MFMA GEMM (csrc/gemm.hip) covers this product.  It is used where an
+    epilogue is fused (entry GEMM + assembly of Linear(2,2,'light'): 6.7 ms vs 5.4 + 5.8 ms; fc_o + bias + skip path);
+    for plain products it runs on par with the library GEMM (3.0-4.6 TB/s of row traffic either way), which stays."""
+    return R >= THIN_MIN_ROWS and lib().hotk_thin_gemm_supported(int(K), int(C)) == 1
+
+
+def thin_gemm(A, W, bias=None, res=None):
+    """Y[R, C] = A[R, K] @ W[K, C] (+ bias) (+ res) in one pass (hotk_thin_gemm_bias); call thin_ok first"""
+    a, lda, R, K = rows2d(A)
+    W = W.contiguous()
+    C = W.size(1)
+    assert W.size(0) == K
+    Y = torch.empty(R, C, dtype=A.dtype, device=A.device)
+    r_, ldr = None, 0
+    if res is not None:
+        r_, ldr, Rr, Cr = rows2d(res)
+        assert Rr == R and Cr == C
+    call('hotk_thin_gemm_bias', 4 * R * (K + C), p(a), lda, p(W), K, C, p(bias), p(r_), ldr, p(Y), C, R)
+    return Y
+
+
 # ------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------
@@ -284,9 +309,15 @@ class Linear22Light(Function):
         yn = xd @ Wn
         x2 = torch.empty(plan.R, 2 * D, dtype=x.dtype, device=dev)
         call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
-        y = x2 @ W[D:3 * D]
-        call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
-             p(b_diag), n, C)
+        if thin_ok(n, 2 * D, C):
+            # entry GEMM with the assembly as its epilogue: y is written once
+            y = torch.empty(n, C, dtype=x.dtype, device=dev)
+            call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
+                 p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n)
+        else:
+            y = x2 @ W[D:3 * D]
+            call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
+                 p(b_diag), n, C)
         ctx.save_for_backward(xd, x2, W)
         ctx.plan, ctx.has_b, ctx.xshape = plan, (b_off is not None, b_diag is not None), x.shape
         return y.view(*x.shape[:-1], C)
@@ -315,7 +346,7 @@ class Linear22Light(Function):
         dx = dW = None
         if ctx.needs_input_grad[0]:
             dxd = dyn @ Wn.t()
-            dx2 = g @ W[D:3 * D].t()
+            dx2 = g @ W[D:3 * D].t()      # plain products stay library GEMMs: measured on par with the thin kernel
             dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
             call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
                  p(dxd), D, p(dx), D, plan.R, D)
@@ -572,10 +603,14 @@ class AttnCore22(Function):
         ws, nws = AttnCore22._workspace(plan, dev)
         call('hotk_attn22_forward', 4 * plan.Ev * (8 * 32 + 10 * 32 + 10 * 32) + 4 * plan.Nn * 384,
              byref(a), p(ws), nws)
-        y = torch.addmm(b_o, att, w_o.t())
-        if padded:
-            y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
-        out = y.add_(h2.view(plan.R, -1)[:, 256:]).view(*h2.shape[:-1], D)
+        skip = h2.view(plan.R, -1)[:, 256:]
+        if not padded and thin_ok(plan.R, 320, D):
+            out = thin_gemm(att, w_o.t(), b_o, skip).view(*h2.shape[:-1], D)      # projection + bias + skip path in one pass
+        else:
+            y = torch.addmm(b_o, att, w_o.t())
+            if padded:
+                y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
+            out = y.add_(skip).view(*h2.shape[:-1], D)
         ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg, phik)
         ctx.plan = plan
         return out

@@ -123,6 +123,21 @@ int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind,
 int hotk_assemble22(float* z, int64_t ld, const float* yn, int64_t ld_yn, const uint8_t* kind, const int32_t* rown,
                     const int32_t* coln, const float* b_off, const float* b_diag, int64_t R, int64_t C, void* stream);
 
+/* Thin GEMMs of the dense projections with the weight resident in LDS (fp32 MFMA) and the row epilogue fused:
+ *   Y[R, C] = A[R, K] @ W[K, C] (+ bias[C]) (+ res[R, C])        W row-major [K, C]
+ * stands in for nn.Linear / `V @ weight` and their data gradients over the ~1e7 entry rows of a batch
+ * (models/sparse/kernelattn.py:46-51,65-82; models/sparse/linear.py:46-48).  Shapes: (K, C) with K in {32, 64, 288, 320}
+ * and C a multiple of {160, 96, 64, 32} resp. (the C1 layer), K*C*4 <= 150 KB; hotk_thin_gemm_supported tells, other
+ * shapes return HOTK_EUNSUPPORTED (the Python layer then uses the library GEMM).  A rows 16-byte aligned.
+ * hotk_linear22_entry_fwd is the entry GEMM of the factored Linear(2,2,'light') with hotk_assemble22's epilogue applied
+ * to the accumulators (one pass over Y instead of three). */
+int hotk_thin_gemm_supported(int64_t K, int64_t C);
+int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
+                        const float* res, int64_t ld_res, float* Y, int64_t ldy, int64_t R, void* stream);
+int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
+                            int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
+                            const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * K2  FAVOR+ random-feature maps (models/common/kernel.py:81-138 fused with the head split, loop mask
  * and padding mask of models/sparse/kernelattncoef.py:19-28).

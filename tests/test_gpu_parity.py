@@ -305,6 +305,54 @@ def test_uniform_extension_vs_reference(name):
         enc(x0, bad)
 
 
+@pytest.mark.parametrize('K,C', [(64, 288), (32, 320), (288, 64), (320, 32), (64, 96)])
+def test_thin_gemm_vs_fp64(K, C):
+    """hand-written LDS-resident-weight MFMA GEMM (csrc/gemm.hip) against an fp64 product, with bias and residual, on a
+    row count that is not a multiple of the 128-row tile, with a padded leading dimension and a column-sliced residual"""
+    _lib, ops, _, _, _, _, _ = _product()
+    assert _lib.lib().hotk_thin_gemm_supported(K, C) == 1 and _lib.lib().hotk_thin_gemm_supported(48, 100) == 0
+    g = torch.Generator().manual_seed(K * 1000 + C)
+    for R in (1, 127, 40037):
+        A = torch.randn(R, K + 4, generator=g).to(DEV)[:, :K]            # ld = K + 4
+        W = torch.randn(K, C, generator=g).to(DEV)
+        b = torch.randn(C, generator=g).to(DEV)
+        res = torch.randn(R, C + 8, generator=g).to(DEV)[:, 8:]
+        ref = (A.double() @ W.double() + b.double() + res.double())
+        y = ops.thin_gemm(A, W, b, res)
+        assert rel_err(y.cpu(), ref.float().cpu()) < TOL, (R, K, C)
+        y0 = ops.thin_gemm(A, W)
+        assert rel_err(y0.cpu(), (A.double() @ W.double()).float().cpu()) < TOL
+
+
+def test_linear22_entry_gemm_matches_assemble_path():
+    """entry GEMM of the factored Linear(2,2,'light') with the fused assembly epilogue (hotk_linear22_entry_fwd) against
+    the library GEMM + hotk_assemble22 path, on ragged graphs (padding rows, one-directional edges), incl. gradients"""
+    _, ops, _, bs, _, ms, _ = _product()
+    nfs, eis, efs, _g = _ragged_case()
+    G0 = bs.make_batch([x.to(DEV) for x in nfs], [x.to(DEV) for x in eis], [x.to(DEV) for x in efs])
+    assert G0.values.size(-1) == 32 and G0.plan.Ev != G0.plan.R
+    torch.manual_seed(3)
+    lin = ms.Linear(2, 2, 32, 288, cfg='light').to(DEV)
+    for p_ in lin.bias.bias:
+        torch.nn.init.normal_(p_, std=0.1)
+    outs = []
+    for thr in (1, 1 << 40):
+        ops.THIN_MIN_ROWS = thr
+        try:
+            x = G0.values.clone().requires_grad_(True)
+            y = lin(bs.batch_like(G0, x, skip_masking=True)).values
+            torch.manual_seed(4)
+            (y * torch.randn_like(y)).sum().backward()
+            outs.append((y.detach(), x.grad.clone(), lin.weight.weight.grad.clone()))
+            lin.zero_grad()
+        finally:
+            ops.THIN_MIN_ROWS = 1 << 15
+    for a_, b_ in zip(outs[0], outs[1]):
+        assert rel_err(a_.cpu(), b_.cpu()) < TOL
+    pad = (G0.plan.kind == 0).view(-1)
+    assert float(outs[0][0].view(-1, 288)[pad].abs().max()) == 0.0
+
+
 def _ba_case(n_graphs, seed):
     from oracle import hot_oracle as O
     rng = np.random.default_rng(seed)
