@@ -32,7 +32,7 @@ BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEAD
 # HBM traffic of the fused core per valid entry on THIS workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
 # profiles/r01_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at 10 M entries
-PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4688, 'hotk_attn22_backward': 7928}
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 5443, 'hotk_attn22_backward': 8805}
 
 
 def build_structure(n_graphs, distinct=512, seed=1234):
@@ -133,6 +133,14 @@ def main():
     G = make_inputs(n_graphs, device, seed=1234 + rank)
     n_entries = sum(G.n_edges)
     n_offdiag = n_entries - sum(G.n_nodes)
+    # K1 (plan: radix sorts, CSR views, transpose map) is per minibatch, not per layer: timed apart from the step
+    from hot_amd.plan import Plan
+    Plan(G.indices, G.n_nodes, G.n_edges)
+    torch.cuda.synchronize()
+    t_k1 = time.perf_counter()
+    Plan(G.indices, G.n_nodes, G.n_edges)
+    torch.cuda.synchronize()
+    k1_ms = (time.perf_counter() - t_k1) * 1e3
     layer = make_layer(device)
     params = [p for p in layer.parameters()]
     x0 = G.values
@@ -191,7 +199,7 @@ def main():
                     'avg_launch_ms': tot_ms / max(calls, 1),
                     'note': 'achieved = algorithmic bytes (operands read once + results written once) of the '
                             'dominant C-ABI kernel / its HIP-event time inside the timed region; the kernel is '
-                            'VALU-bound (fp32 vector ALU 55-70 % busy, HBM traffic 1.15x algorithmic), see DESIGN.md 5'}
+                            'instruction-issue bound (HBM traffic 1.15-1.25x algorithmic at 2-3 TB/s), see DESIGN.md 4'}
         line = {
             'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': value, 'unit': 'entries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
@@ -204,6 +212,7 @@ def main():
                                'note': 'SURVEY 8d whole-layer figure: attention-core algorithmic bytes x entries/s '
                                        '/ 8 TB/s, GEMM time included in the denominator'},
             'roofline': roof,
+            'k1_plan_build_ms': round(k1_ms, 3),
             'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
         }
         if args.no_cpu_baseline or world > 1:
