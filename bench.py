@@ -37,7 +37,7 @@ PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 5443, 'hotk_attn22_backwar
 
 def build_structure(n_graphs, distinct=512, seed=1234):
     """edge_index [2, n_graphs*590] (local ids) from `distinct` seeded BA graphs, tiled"""
-    from oracle.hot_oracle import ba_edges   # generator only (shared with the tests); no compute is routed here
+    from hot_amd.utils.graphs import ba_edges
     rng = np.random.default_rng(seed)
     base = [ba_edges(N_NODES, BA_M, rng) for _ in range(min(distinct, n_graphs))]
     reps = (n_graphs + len(base) - 1) // len(base)
