@@ -19,6 +19,7 @@ def build(force=False, verbose=True):
         return OUT
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
+           '-mllvm', '-amdgpu-mfma-vgpr-form',   # MFMA results in VGPRs: no v_accvgpr_read/write around the tile code
            '-o', OUT] + srcs
     if verbose:
         print(' '.join(cmd), flush=True)

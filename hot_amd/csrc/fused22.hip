@@ -19,6 +19,7 @@
 //             sum_k row_ror_k(phi) * rot[k]  = 16 DPP multiply-adds, with no reduction tree, select or LDS traffic.
 // The same rotated form of the projection matrix turns  d(raw q)[j] = sum_mm dpre[mm] P[mm][j]  into 16 DPP FMAs.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -300,6 +301,35 @@ __device__ __forceinline__ void pipeline4(int cnt, LoadF load, UseF use) {
   }
 }
 
+// depth-8 variant for light consumers (the MFMA accumulation: three loads and two instructions per item)
+template <int NR, class LoadF, class UseF>
+__device__ __forceinline__ void pipeline8(int cnt, LoadF load, UseF use) {
+  if (cnt <= 0) return;
+  const int last = cnt - 1;
+  float r0[NR], r1[NR], r2[NR], r3[NR], r4[NR], r5[NR], r6[NR], r7[NR];
+#define HOTK_PL(i, r) load((i) < last ? (i) : last, r)
+  HOTK_PL(0, r0); HOTK_PL(1, r1); HOTK_PL(2, r2); HOTK_PL(3, r3); HOTK_PL(4, r4); HOTK_PL(5, r5); HOTK_PL(6, r6);
+  for (int k = 0; k < cnt; k += 8) {
+    HOTK_PL(k + 7, r7);
+    use(k, r0);
+    HOTK_PL(k + 8, r0);
+    if (k + 1 < cnt) use(k + 1, r1);
+    HOTK_PL(k + 9, r1);
+    if (k + 2 < cnt) use(k + 2, r2);
+    HOTK_PL(k + 10, r2);
+    if (k + 3 < cnt) use(k + 3, r3);
+    HOTK_PL(k + 11, r3);
+    if (k + 4 < cnt) use(k + 4, r4);
+    HOTK_PL(k + 12, r4);
+    if (k + 5 < cnt) use(k + 5, r5);
+    HOTK_PL(k + 13, r5);
+    if (k + 6 < cnt) use(k + 6, r6);
+    HOTK_PL(k + 14, r6);
+    if (k + 7 < cnt) use(k + 7, r7);
+  }
+#undef HOTK_PL
+}
+
 // depth-2 variant for register-heavy consumers
 template <int NR, class LoadF, class UseF>
 __device__ __forceinline__ void pipeline2(int cnt, LoadF load, UseF use) {
@@ -528,7 +558,7 @@ __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float*
   });
 }
 
-template <int P>
+template <int P, bool GT = true>   // GT: also the per-graph terms and the zero fill (false: k_graph_apply_fwd_t does them)
 __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
@@ -550,17 +580,19 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
       const float* q = a.h1 + n * a.ld_h1;
       float* o = a.att + rowoff(a.diag_pos[n], a.ld_att);
       float r[2] = {q[L.lane], q[64 + L.lane]};
-      float g0[NM], g1[NM];
-      kvg_load_rot(L, kvg_slot(a.kvg, b, 0), g0);
-      kvg_load_rot(L, kvg_slot(a.kvg, b, 1), g1);
       stage_put<2>(L, stage, r);
       float x[8];
       slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 0 * SLOT);
       slice8(L, stage + 1 * SLOT, x); apply_fwd(L, x, rot1, o + 1 * SLOT);
-      slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 6 * SLOT);
-      slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 7 * SLOT);
-      zero_slots(L, o + 2 * SLOT, 4);
-      zero_slots(L, o + 8 * SLOT, 2);
+      if (GT) {
+        float g0[NM], g1[NM];
+        kvg_load_rot(L, kvg_slot(a.kvg, b, 0), g0);
+        kvg_load_rot(L, kvg_slot(a.kvg, b, 1), g1);
+        slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 6 * SLOT);
+        slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 7 * SLOT);
+        zero_slots(L, o + 2 * SLOT, 4);
+        zero_slots(L, o + 8 * SLOT, 2);
+      }
     } else if (P == 1) {
       // entries of column n: terms 3, 5 (this node's sums) and 9, 10 (graph sums)
       const int64_t b = n / a.Nmax;
@@ -855,6 +887,321 @@ __global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
   }
 }
 
+// ================================================================================================
+// MFMA tile kernels (parts 1 and 2 of the node segments).  All small contractions of an entry -- the 8 -> 16 random
+// feature projection and the 16-feature x 9-channel key-value products -- run on the matrix cores in exact f32
+// (v_mfma_f32_16x16x4_f32 / v_mfma_f32_16x16x1_4b_f32), 16 entries of a segment at a time:
+//   "T layout" of a 16 x 16 matrix M[p][q]: lane (g, x) = (lane >> 4, lane & 15), register r holds M[4g + r][x].
+//   One MFMA group computes  OUT[i][j] = sum_p TA[p][i] * TB[p][j]  from two T-layout operands and leaves OUT in the
+//   T layout again, so a result feeds the next product that sums over its ROW index with no lane movement:
+//     accumulate  KV[mm][c]  = sum_e phiK[e][mm] * [V | 1][e][c]   (4-block form: one instruction per entry, all heads)
+//     project     PRE[mm][t] = sum_j P[mm][j] * q[t][j]            (entries t on the lanes)
+//     apply       O[t][c]    = sum_mm phi(PRE)[mm][t] * KV[mm][c]  (channels on the lanes, entries in (g, r))
+//   Key-value sums are accumulated in entry order by a k-ordered fmaf chain, as the VALU kernels do.
+// Two slots are processed as a pair: slot A keeps its 8 value channels on lanes x < 8 and the normaliser on x >= 8,
+// slot B the other way round, so that one full-width store writes both results.
+// ================================================================================================
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+struct LaneT {
+  int lane, g, x;
+  float pt0, pt1;  // projection as the TA operand of PRE: P[x][2g], P[x][2g + 1] (scaled)
+};
+__device__ __forceinline__ LaneT make_lane_t(const float* __restrict__ proj) {
+  LaneT L;
+  L.lane = threadIdx.x & 63;
+  L.g = L.lane >> 4;
+  L.x = L.lane & 15;
+  L.pt0 = proj[L.x * DH + 2 * L.g] * PSCALE;
+  L.pt1 = proj[L.x * DH + 2 * L.g + 1] * PSCALE;
+  return L;
+}
+__device__ __forceinline__ f4v mfma4(float a, float b, f4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f16v mfma4b(float a, float b, f16v c) { return __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f16v zero16() {
+  f16v z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// the two column sums of part P for node n in the T layout (register 4h + r: feature 4g + r of head h, channel on x):
+// kv0 with values on x < 8 / key sum on x >= 8, kv1 with values on x >= 8 / key sum on x < 8
+template <int P>
+__device__ __forceinline__ void seg_accumulate_t(const LaneT& L, const A& a, int32_t n, f16v& kv0, f16v& kv1) {
+  kv0 = zero16();
+  kv1 = zero16();
+  const bool lo8 = L.x < 8;
+  const float one0 = lo8 ? 0.f : 1.f, one1 = lo8 ? 1.f : 0.f;
+  const int vcol = (lo8 ? 2 * P * SLOT : (2 * P + 1) * SLOT) + L.g * 8 + (L.x & 7);
+  const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
+  Lane L0;
+  L0.lane = L.lane;
+  for (int32_t base = c0; base < c1; base += 64) {
+    const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
+    const ColBlock cb = col_block(L0, a, base, cnt);
+    auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
+      const int32_t e = rl(cb.e, k), i = rl(cb.i, k), te = rl(cb.te, k);
+      const float* pk = a.phik + rowoff(i, a.ld_phik) + 2 * P * 64 + L.lane;
+      r[0] = pk[0];
+      r[1] = pk[64];
+      const int32_t tr = te < 0 ? e : te;   // a missing transposed entry is masked at use time
+      const int64_t o0 = rowoff(P == 2 ? tr : e, a.ld_v), o1 = rowoff(P == 2 ? e : tr, a.ld_v);
+      r[2] = a.v[(lo8 ? o0 : o1) + vcol];
+    };
+    auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
+      const bool ok = rl(cb.te, k) >= 0;
+      const float b0 = (lo8 && (P != 2 || ok)) ? r[2] : one0;
+      const float b1 = (!lo8 && (P == 2 || ok)) ? r[2] : one1;
+      kv0 = mfma4b(r[0], b0, kv0);
+      kv1 = mfma4b(r[1], b1, kv1);
+    };
+    pipeline8<3>(cnt, load, use);
+  }
+}
+
+// per-graph sum `slot` (feature-major part of kvg) in the T layout; HI: values on x >= 8
+template <bool HI>
+__device__ __forceinline__ f16v kvg_load_t(const LaneT& L, const float* __restrict__ slot) {
+  const int c = HI ? (L.x >= 8 ? L.x - 8 : NC) : (L.x < 8 ? L.x : NC);
+  f16v kv;
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    const float4 t = ld4(slot + c * 64 + h * 16 + 4 * L.g);
+    kv[4 * h + 0] = t.x; kv[4 * h + 1] = t.y; kv[4 * h + 2] = t.z; kv[4 * h + 3] = t.w;
+  }
+  return kv;
+}
+
+// max(a, b) for b > 0 and a not NaN as an integer max (negative floats are negative integers): fmaxf would put a
+// canonicalising self-max in front, and an asm v_max would hide the MFMA -> VALU hazard from the compiler
+__device__ __forceinline__ float max_pos(float a, float b) {
+  const int ia = __float_as_int(a), ib = __float_as_int(b);
+  return __int_as_float(ia > ib ? ia : ib);
+}
+
+// Tile I/O goes through a wave-private LDS image of 16 rows x 64 floats (+4 floats of padding per row), so that global
+// memory only sees full 128-B / 256-B row pieces (fragment-shaped accesses -- 16 rows x 32 B per instruction -- keep
+// the address path busy several times longer for the same bytes): lane (g, x) moves float4 number x of rows 4g + r.
+constexpr int TS = 68;               // floats per staged row: b64 fragment reads of 32 lanes hit 64 distinct banks
+constexpr int TILE_FLOATS = 16 * TS;
+struct TileRaw { float4 r[4]; };
+struct TileQ { float2 a[NH], b[NH]; };
+
+// rows[r]: row of entry 4g + r; col: first of the 64 columns (two adjacent slots)
+__device__ __forceinline__ void tile_raw_load(const LaneT& L, const float* const (&rows)[4], int col, TileRaw& t) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) t.r[r] = ld4(rows[r] + col + 4 * L.x);
+}
+// registers -> LDS image -> fragments: entry t = x, head h, elements 2g, 2g + 1 of the head slice of slots a | b
+__device__ __forceinline__ void tile_fragments(const LaneT& L, float* tile, const TileRaw& t, TileQ& q) {
+  wave_fence();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(tile + (4 * L.g + r) * TS + 4 * L.x) = t.r[r];
+  wave_fence();
+#pragma unroll
+  for (int h = 0; h < NH; ++h) {
+    q.a[h] = *reinterpret_cast<const float2*>(tile + L.x * TS + h * 8 + 2 * L.g);
+    q.b[h] = *reinterpret_cast<const float2*>(tile + L.x * TS + SLOT + h * 8 + 2 * L.g);
+  }
+}
+
+// 16 entries x 2 slots: out = phi(q).KV / (phi(q).ks).  q: the tile's raw queries (entry t = x); orow[r]: output row of
+// entry t = 4g + r; oa / ob: output columns of the two slots.  Straight-line code: every lane stores (positions
+// without an entry of their own repeat another entry of the segment, see tile_rows).  Two heads at a time: four
+// independent MFMA chains cover the 40-cycle dependent latency and the live set stays small.
+__device__ __forceinline__ void tile_apply_pair_fwd(const LaneT& L, float* tile, const TileQ& q, const f16v& kvA,
+                                                    const f16v& kvB, float* const (&orow)[4], int oa, int ob) {
+  const bool lo8 = L.x < 8;
+  const f4v eps4 = {PHI_EPS, PHI_EPS, PHI_EPS, PHI_EPS};
+  const f4v z4 = {0.f, 0.f, 0.f, 0.f};
+  wave_fence();   // the fragment reads of this tile are done before its results overwrite the image
+  float* tw = tile + 4 * L.g * TS + (lo8 ? L.x : SLOT + L.x - 8);
+#pragma unroll
+  for (int h0 = 0; h0 < NH; h0 += 2) {
+    f4v pA[2], pB[2], oA[2], oB[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {   // phi = max(pre, 0) + eps = max(pre + eps, eps)
+      pA[i] = mfma4(L.pt0, q.a[h0 + i].x, eps4);
+      pB[i] = mfma4(L.pt0, q.b[h0 + i].x, eps4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      pA[i] = mfma4(L.pt1, q.a[h0 + i].y, pA[i]);
+      pB[i] = mfma4(L.pt1, q.b[h0 + i].y, pB[i]);
+      oA[i] = z4;
+      oB[i] = z4;
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        oA[i] = mfma4(max_pos(pA[i][s], PHI_EPS), kvA[4 * (h0 + i) + s], oA[i]);
+        oB[i] = mfma4(max_pos(pB[i][s], PHI_EPS), kvB[4 * (h0 + i) + s], oB[i]);
+      }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float num = lo8 ? oA[i][r] : oB[i][r];
+        const float den = max_pos(ror<8>(lo8 ? oB[i][r] : oA[i][r]), 1e-30f);   // see apply_fwd: empty key set -> 0
+        tw[r * TS + (h0 + i) * 8] = num * __builtin_amdgcn_rcpf(den);
+      }
+  }
+  wave_fence();
+  const int ocol = lo8 ? oa + 4 * L.x : ob + 4 * (L.x - 8);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    *reinterpret_cast<float4*>(orow[r] + ocol) = *reinterpret_cast<const float4*>(tile + (4 * L.g + r) * TS + 4 * L.x);
+}
+
+// zero `nf4` float4s (a multiple of 16) at column `col` of the four rows of this lane group (16 lanes per row)
+__device__ __forceinline__ void tile_zero_rows(const LaneT& L, float* const (&orow)[4], int col, int nf4) {
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+    for (int j = L.x; j < nf4; j += 16) reinterpret_cast<float4*>(orow[r] + col)[j] = z;
+}
+
+// Entry rows of one 16-position tile [t0, t0 + 16) of a non-empty segment [.., c1) (column segment for P == 1, row
+// segment for P == 2): eb[r] = row of position t0 + 4g + r.  Positions past the end of the segment and diagonal
+// entries are replaced by `sub`, an off-diagonal entry of the same segment: they recompute and rewrite that entry's
+// results (same values, same addresses), which keeps the tile code free of branches.  FIRST: also finds sub (a
+// segment holds at most one diagonal entry, so one of its first two positions is off-diagonal if any is; -1: none).
+template <int P, bool FIRST>
+__device__ __forceinline__ void tile_rows(const LaneT& L, const A& a, int32_t t0, int32_t c1, int32_t& sub, int32_t (&eb)[4]) {
+  const int32_t last = c1 - 1;
+  int32_t pb[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) pb[r] = t0 + 4 * L.g + r < last ? t0 + 4 * L.g + r : last;
+  int32_t rb[4];   // entry row, or a negative value for a diagonal entry
+  if (P == 1) {
+    const int4* rec = reinterpret_cast<const int4*>(a.col_rec);
+    int4 qb[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) qb[r] = rec[pb[r]];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[r] = qb[r].w == 2 ? qb[r].x : -1;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rb[r] = a.row_rec[pb[r]];
+  }
+  if (FIRST) {
+    const int32_t s0 = rl(rb[0], 0), s1 = rl(rb[1], 0);   // positions t0 and t0 + 1 (lane group 0)
+    sub = s0 >= 0 ? s0 : (t0 + 1 < c1 ? s1 : -1);
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) eb[r] = (rb[r] >= 0 && t0 + 4 * L.g + r <= last) ? rb[r] : sub;
+}
+
+template <int P>
+__global__ __launch_bounds__(TPB, 4) void k_segt_fwd(A a) {
+  __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
+  float* tile = tile_all[threadIdx.x >> 6];
+  const LaneT L = make_lane_t(a.proj);
+  constexpr int QC = P == 1 ? 0 : 2 * SLOT;                                             // raw query slots 0, 1 / 2, 3
+  constexpr int OA = P == 1 ? 2 * SLOT : 3 * SLOT, OB = P == 1 ? 4 * SLOT : 5 * SLOT;   // terms 3, 5 / 4, 6
+  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+    // P == 1: entries of column n, terms 3, 5;  P == 2: entries of row n, terms 4, 6 (sums of their ROW node)
+    const int32_t c0 = P == 1 ? a.col_ptr[n] : a.row_ptr[n];
+    int32_t c1 = P == 1 ? a.col_ptr[n + 1] : a.row_ptr[n + 1];
+    if (c1 <= c0) continue;   // padding node
+    int32_t sub, eb[4];
+    tile_rows<P, true>(L, a, c0, c1, sub, eb);
+    if (sub < 0) {   // no off-diagonal entry: nothing to write; keep the loads below on valid addresses
+      c1 = c0;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) eb[r] = 0;
+    }
+    TileRaw raw;
+    {
+      const float* rows[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rows[r] = a.h2 + rowoff(eb[r], a.ld_h2);
+      tile_raw_load(L, rows, QC, raw);   // in flight during the accumulation
+    }
+    f16v kv0, kv1;
+    seg_accumulate_t<P>(L, a, (int32_t)n, kv0, kv1);
+    for (int32_t t0 = c0; t0 < c1; t0 += 16) {
+      if (t0 != c0) {
+        tile_rows<P, false>(L, a, t0, c1, sub, eb);
+        const float* rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[r] = a.h2 + rowoff(eb[r], a.ld_h2);
+        tile_raw_load(L, rows, QC, raw);
+      }
+      float* orow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) orow[r] = a.att + rowoff(eb[r], a.ld_att);
+      TileQ q;
+      tile_fragments(L, tile, raw, q);
+      tile_apply_pair_fwd(L, tile, q, kv0, kv1, orow, OA, OB);
+    }
+  }
+}
+
+// Per-graph terms, application side: consecutive rows of one graph share the graph's two key-value sums, so this is a
+// streaming kernel over 16-row tiles.  Diagonal rows (node queries q1 slots 2, 3 against kvg slots 0, 1 -> terms 7, 8)
+// and off-diagonal rows (entry queries q2 slots 4, 5 against kvg slots 2, 3 -> terms 9, 10); also zero-fills the terms
+// that do not exist on a row kind (1, 2, 7, 8 off the diagonal; 3..6, 9, 10 on it).
+constexpr int GA_TILES = 8;   // 16-row tiles per wave
+__global__ __launch_bounds__(TPB, 4) void k_graph_apply_fwd_t(A a) {
+  __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
+  float* tile = tile_all[threadIdx.x >> 6];
+  const LaneT L = make_lane_t(a.proj);
+  const int64_t nd = (a.Nmax + 16 * GA_TILES - 1) / (16 * GA_TILES), no = (a.Emax + 16 * GA_TILES - 1) / (16 * GA_TILES);
+  const int64_t nwork = a.B * (nd + no);
+  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
+    const int64_t b = w / (nd + no), k = w - b * (nd + no);
+    const bool diag = k < nd;
+    const int32_t nn = a.n_nodes[b], ne = a.n_entries[b];
+    // rows [r0, r1) relative to the graph's first row
+    const int32_t lo = diag ? 0 : nn, hi = diag ? nn : ne;
+    const int32_t r0 = lo + (int32_t)(diag ? k : k - nd) * 16 * GA_TILES;
+    if (r0 >= hi) continue;
+    const int32_t r1 = r0 + 16 * GA_TILES < hi ? r0 + 16 * GA_TILES : hi;
+    const int32_t last = r1 - 1;   // rows past the end repeat the last row
+    const int64_t ebase = b * a.Emax, nbase = b * a.Nmax;
+    const float* qbase = diag ? a.h1 + nbase * a.ld_h1 : a.h2 + ebase * a.ld_h2;
+    const int64_t ldq = diag ? a.ld_h1 : a.ld_h2;
+    const int qc = diag ? 2 * SLOT : 4 * SLOT;
+    const int oa = diag ? 6 * SLOT : 8 * SLOT, ob = oa + SLOT;
+    auto load_tile = [&](int32_t t0, TileRaw& raw) __attribute__((always_inline)) {
+      const float* rows[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int32_t tb = t0 + 4 * L.g + r < last ? t0 + 4 * L.g + r : last;
+        rows[r] = qbase + (diag ? tb : tb) * ldq;
+      }
+      tile_raw_load(L, rows, qc, raw);
+    };
+    TileRaw raw;
+    load_tile(r0, raw);
+    const f16v g0 = kvg_load_t<false>(L, kvg_slot(a.kvg, b, diag ? 0 : 2));
+    const f16v g1 = kvg_load_t<true>(L, kvg_slot(a.kvg, b, diag ? 1 : 3));
+    for (int32_t t0 = r0; t0 < r1; t0 += 16) {
+      float* orow[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int32_t tb = t0 + 4 * L.g + r < last ? t0 + 4 * L.g + r : last;
+        orow[r] = a.att + (ebase + tb) * a.ld_att;
+      }
+      TileQ q;
+      tile_fragments(L, tile, raw, q);
+      load_tile(t0 + 16, raw);   // next tile in flight during this tile's products (the last one re-reads the last row)
+      tile_apply_pair_fwd(L, tile, q, g0, g1, orow, oa, ob);
+      if (diag) {
+        tile_zero_rows(L, orow, 2 * SLOT, 32);
+        tile_zero_rows(L, orow, 8 * SLOT, 16);
+      } else {
+        tile_zero_rows(L, orow, 0, 16);
+        tile_zero_rows(L, orow, 6 * SLOT, 16);
+      }
+    }
+  }
+}
+
 int check_args(const A* a) {
   if (!a) return HOTK_EINVAL;
   if (a->H != NH || a->m != NM || a->d_head != DH || a->c != NC) return HOTK_EUNSUPPORTED;
@@ -872,6 +1219,12 @@ int check_args(const A* a) {
     if (ld < 0 || ld > INT32_MAX) return HOTK_EINVAL;
   if (!hotk_aligned16(a->h1) || !hotk_aligned16(a->h2) || !hotk_aligned16(a->v)) return HOTK_EINVAL;
   return HOTK_OK;
+}
+
+// HOTK_CORE=valu selects the VALU/DPP node-segment kernels instead of the MFMA tile kernels (A/B measurements)
+bool core_valu() {
+  static const int v = [] { const char* e = getenv("HOTK_CORE"); return (e && e[0] == 'v') ? 1 : 0; }();
+  return v != 0;
 }
 
 void chunking(int64_t Emax, int* cpg, int* rows) {
@@ -908,9 +1261,18 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
   hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4, 1, 256 * 16)), dim3(256), 0, st, part, a->kvg, a->B, cpg, 0);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
-  hipLaunchKernelGGL(k_seg_fwd<1>, gseg, dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_fwd<2>, gseg, dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_fwd<0>, gseg, dim3(TPB), 0, st, *a);
+  if (core_valu()) {
+    hipLaunchKernelGGL((k_seg_fwd<1, true>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<2, true>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<0, true>), gseg, dim3(TPB), 0, st, *a);
+  } else {
+    const int64_t per = 16 * GA_TILES;
+    const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
+    hipLaunchKernelGGL(k_graph_apply_fwd_t, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL(k_segt_fwd<1>, gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL(k_segt_fwd<2>, gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<0, false>), gseg, dim3(TPB), 0, st, *a);
+  }
   return hotk_launch_status();
 }
 
