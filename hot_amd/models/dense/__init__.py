@@ -1,0 +1,3 @@
+from .linear import Linear  # noqa: F401
+from .kernelattn import KernelSelfAttn  # noqa: F401
+from .f import Apply, Nonlinear, Add  # noqa: F401

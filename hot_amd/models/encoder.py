@@ -7,11 +7,15 @@ from typing import Union
 
 import torch.nn as nn
 
-from .sparse.kernelattn import KernelSelfAttn
+from .sparse.kernelattn import KernelSelfAttn as S_KernelSelfAttn
 from .sparse.attn import SelfAttn
-from .sparse.f import Apply, Add
-from .sparse.linear import Linear
+from .sparse.f import Apply as S_Apply, Add as S_Add
+from .sparse.linear import Linear as S_Linear
+from .dense.kernelattn import KernelSelfAttn as D_KernelSelfAttn
+from .dense.f import Apply as D_Apply, Add as D_Add
+from .dense.linear import Linear as D_Linear
 from ..batch.sparse import Batch as S
+from ..batch.dense import Batch as D
 from .common.kernel import KernelFeatureMap
 
 
@@ -21,12 +25,15 @@ class EncLayer(nn.Module):
         super().__init__()
         assert cfg in ('default', 'local')
         assert att_cfg in ('default', 'kernel', 'generalized_kernel')
-        if not sparse:
-            raise NotImplementedError('hot_amd implements the sparse layout only')
         if att_cfg == 'default' and ord_out != 0:
             raise NotImplementedError('softmax SelfAttn with an order >= 1 output is quadratic in |E| and not part of '
                                       'the linear-cost path (use att_cfg="kernel" / "generalized_kernel")')
-        self.add = Add()
+        if not sparse and ord_out == 0:
+            raise NotImplementedError('the order-0 softmax readout is built for the sparse layout only')
+        KernelSelfAttn = S_KernelSelfAttn if sparse else D_KernelSelfAttn
+        Linear = S_Linear if sparse else D_Linear
+        Apply = S_Apply if sparse else D_Apply
+        self.add = S_Add() if sparse else D_Add()
         self.sparse = sparse
         self.ln = Apply(nn.LayerNorm(dim_in))
         # (dim_qk, dim_v) land in KernelSelfAttn's (dim_v, dim_qk) slots, exactly as in the reference (encoder.py:37)
@@ -56,8 +63,8 @@ class Encoder(nn.Module):
                  readout_dim_qk, readout_dim_v, readout_n_heads, enc_cfg='default', att_cfg='default',
                  drop_input=0., dropout=0., drop_mu=0., sparse=True):
         super().__init__()
-        if not sparse:
-            raise NotImplementedError('hot_amd implements the sparse layout only')
+        Linear = S_Linear if sparse else D_Linear
+        Apply = S_Apply if sparse else D_Apply
         self.sparse = sparse
         self.input = nn.Sequential(
             Linear(ord_in, ord_in, dim_in, dim_hidden, cfg='light'),
@@ -77,8 +84,8 @@ class Encoder(nn.Module):
         self.layers = nn.Sequential(*layers)
         self.output = Apply(nn.Sequential(nn.LayerNorm(dim_hidden), nn.Linear(dim_hidden, dim_out)))
 
-    def forward(self, G: S):
-        assert isinstance(G, S)
+    def forward(self, G: Union[S, D]):
+        assert isinstance(G, S if self.sparse else D)
         if (self.feature_map is not None) and (not self.skip_redraw_projections):
             self.feature_map.redraw_projections()
         G = self.input(G)

@@ -357,6 +357,42 @@ class Linear22Light(Function):
         return dx, dW, db_off, db_diag, None
 
 
+class Assemble12(Function):
+    """y[(i,j)] = yn[i][C:2C] + yn[j][2C:3C] + b_off off the diagonal, y[(v,v)] = yn[v][0:C] + b_diag, padding rows zero:
+    the broadcast step of an order-1 -> order-2 linear layer (models/dense/linear.py:92-111 `_1_to_2`, get_output and
+    the order-2 bias :214-225) in factored form -- the node-level blocks are projected per node ([Nn, 3C]) and this
+    kernel (hotk_assemble22 on a zero tensor) gathers them back.  Backward: the node gradients are dy on the node's
+    diagonal entry and the row / column segment sums of dy over the off-diagonal entries."""
+
+    @staticmethod
+    def forward(ctx, yn, b_off, b_diag, plan):
+        _lib.require_device(yn)
+        C = yn.size(-1) // 3
+        assert yn.size(-1) == 3 * C and yn.numel() == plan.Nn * 3 * C
+        yn = yn.contiguous()
+        y = torch.zeros(plan.R, C, dtype=yn.dtype, device=yn.device)
+        call('hotk_assemble22', 8 * plan.R * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
+             p(b_diag), plan.R, C)
+        ctx.plan, ctx.has_b, ctx.C = plan, (b_off is not None, b_diag is not None), C
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, C = ctx.plan, ctx.C
+        g = g.contiguous().view(plan.R, C)
+        if plan.Ev != plan.R:
+            g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
+        long_seg = max(plan.max_row_deg, plan.max_col_deg) > SEG_CHUNK
+        dyn = (torch.zeros if long_seg else torch.empty)(plan.Nn, 3 * C, dtype=g.dtype, device=g.device)
+        call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
+        for k, (beg, end, perm, maxlen) in ((1, plan.row_seg()), (2, plan.col_seg())):
+            call('hotk_seg_sum_rows', 4 * C * (plan.Ev + plan.Nn), p(g), C, p(beg), p(end), p(perm), p(plan.kind),
+                 KEEP_OFFDIAG, c_void_p_of(dyn, k * C), 3 * C, plan.Nn, C, maxlen)
+        db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
+        db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
+        return dyn, db_off, db_diag, None
+
+
 class BiasMask(Function):
     """y + bias by row kind, padding rows zeroed, in place on y (a fresh GEMM output).
     Stands in for _Bias._1/_2 followed by Linear's apply_mask(0) (models/sparse/linear.py:293-306,345-346)."""

@@ -139,3 +139,67 @@ class NodePlan:
 
     def unit_seg(self, n):
         return self.iota[:n], self.iota[1:n + 1], None, 1
+
+
+class DensePlan:
+    """Segment plan of a DENSE order-2 batch [B, N, N, D] (hot_pytorch/batch/dense.py:9-58) read as rows
+    r = (b*N + i)*N + j: the same fields as Plan (kinds, node rows, transposed row, CSR views by row and by column
+    node, graph ranges), so the plan-driven kernels run on the dense layout unchanged.  Every (i, j) with
+    i, j < n_b is a valid entry (diagonal where i == j); the rest of the N x N block is padding.  Pure index
+    bookkeeping (torch ops on `device`), built once per (n_nodes, N) and shared by every re-wrapped batch.  The
+    kernels that rely on the sparse layout invariant (the fused 2->2 core) do not take this plan."""
+
+    def __init__(self, n_nodes, N, device):
+        n_nodes = [int(x) for x in n_nodes]
+        B = len(n_nodes)
+        assert B == 0 or max(n_nodes) <= N
+        self.B, self.Nmax, self.Emax = B, N, N * N
+        self.R, self.Nn = B * N * N, B * N
+        assert self.R < 2 ** 31
+        dev = torch.device(device)
+        i32 = dict(dtype=torch.int32, device=dev)
+        nn = torch.as_tensor(n_nodes, dtype=torch.long, device=dev)
+        ar = torch.arange(N, device=dev)
+        vn = ar[None, :] < nn[:, None]                                   # [B, N] valid nodes
+        valid = vn[:, :, None] & vn[:, None, :]                          # [B, N, N]
+        eye = torch.eye(N, dtype=torch.bool, device=dev)[None]
+        kind = torch.where(valid, torch.where(eye, 1, 2), 0)
+        self.kind = kind.reshape(-1).to(torch.uint8)
+        self.nkind = vn.reshape(-1).to(torch.uint8)
+        base_n = (torch.arange(B, device=dev) * N)[:, None, None]
+        base_e = (torch.arange(B, device=dev) * N * N)[:, None, None]
+        I, J = ar[None, :, None].expand(B, N, N), ar[None, None, :].expand(B, N, N)
+        neg = torch.full((B, N, N), -1, device=dev)
+        self.rown = torch.where(valid, base_n + I, neg).reshape(-1).to(torch.int32)
+        self.coln = torch.where(valid, base_n + J, neg).reshape(-1).to(torch.int32)
+        self.tpos = torch.where(valid, base_e + J * N + I, neg).reshape(-1).to(torch.int32)
+        dpos = (torch.arange(B, device=dev) * N * N)[:, None] + ar[None, :] * (N + 1)
+        self.diag_pos = torch.where(vn, dpos, torch.full_like(dpos, -1)).reshape(-1).to(torch.int32)
+        self.diag_node = torch.where(self.kind == 1, self.rown, torch.full_like(self.rown, -1))
+        # CSR views: entries of row node (b, i) are the rows (b, i, j < n_b); of column node (b, j) the rows (b, i < n_b, j)
+        cnt = torch.where(vn, nn[:, None].expand(B, N), torch.zeros_like(vn, dtype=torch.long)).reshape(-1)
+        ptr = torch.zeros(self.Nn + 1, dtype=torch.long, device=dev)
+        ptr[1:] = torch.cumsum(cnt, 0)
+        self.row_ptr = ptr.to(torch.int32)
+        self.col_ptr = self.row_ptr.clone()
+        rows = torch.arange(self.R, device=dev).view(B, N, N)
+        self.row_perm = rows[valid].to(torch.int32)                                       # row-major: grouped by i
+        self.col_perm = rows.transpose(1, 2)[valid.transpose(1, 2)].to(torch.int32)       # grouped by j
+        self.Ev = int(self.row_perm.numel())
+        if self.Ev == 0:
+            self.row_perm = torch.zeros(1, **i32)
+            self.col_perm = torch.zeros(1, **i32)
+        self.max_row_deg = self.max_col_deg = max(n_nodes) if B else 0
+        eb = torch.arange(B, device=dev) * N * N
+        nb = torch.arange(B, device=dev) * N
+        self.g_ebeg, self.g_eend = eb.to(torch.int32), (eb + N * N).to(torch.int32)      # padding inside: masked by kind
+        self.g_nbeg, self.g_nend = nb.to(torch.int32), (nb + nn).to(torch.int32)
+        self.n_nodes_dev = nn.to(torch.int32)
+        self.n_entries_dev = (nn * nn).to(torch.int32)
+        self.iota = torch.arange(max(self.R, self.Nn) + 1, **i32)
+        self.device = dev
+
+    col_seg = Plan.col_seg
+    row_seg = Plan.row_seg
+    graph_seg = Plan.graph_seg
+    unit_seg = Plan.unit_seg

@@ -333,8 +333,63 @@ def dump_uniform(name, N, B, k, D, dqk, dv, H, seed):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def dump_dense(name, n_nodes, N, D, dqk, dv, H, dff, seed):
+    """F11: the dense layout (batch/dense.py, models/dense/*, 8f-4 / config C3: set input -> graph output): Linear
+    1->1 / 1->2 / 2->2 / 2->1 / 2->0 / 1->0 in both cfgs on [B,N,D] / [B,N,N,D] batches with ragged n_nodes,
+    KernelSelfAttn 1->1 and 1->2 with the generalized kernel, d / v2d / nd / t, and a whole
+    Encoder(1, 2, [1, 1], ..., sparse=False) as set-to-graph/main/models/model.py:9-30 builds it."""
+    from hot_pytorch.batch import dense as DB
+    from hot_pytorch.models.dense.linear import Linear as DLinear
+    from hot_pytorch.models.dense.kernelattn import KernelSelfAttn as DAttn
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    B = len(n_nodes)
+    x1 = torch.randn(B, N, D, generator=g)
+    x2 = torch.randn(B, N, N, D, generator=g)
+    out = {'x1': npy(x1), 'x2': npy(x2), 'n_nodes': np.array(n_nodes), 'dims': np.array([N, D, dqk, dv, H, dff])}
+
+    def run(tag, mod, order):
+        for n_, p in mod.named_parameters():
+            if 'bias' in n_ and p.dim() == 1:
+                torch.nn.init.normal_(p, std=0.1)
+        x = (x1 if order == 1 else x2).clone().requires_grad_(True)
+        y = mod(DB.Batch(x, n_nodes))
+        ya = y if isinstance(y, torch.Tensor) else y.A
+        R = torch.randn(ya.shape, generator=g)
+        (ya * R).sum().backward()
+        for k_, v in mod.state_dict().items():
+            out[f'{tag}/sd/{k_}'] = npy(v)
+        for k_, p in mod.named_parameters():
+            out[f'{tag}/grad/{k_}'] = npy(p.grad)
+        out[f'{tag}/y'] = npy(ya); out[f'{tag}/R'] = npy(R); out[f'{tag}/gx'] = npy(x.grad)
+        if not isinstance(y, torch.Tensor):
+            out[f'{tag}/mask'] = npy(y.mask)
+
+    G2 = DB.Batch(x2.clone(), n_nodes)
+    out['util/d'] = npy(DB.d(G2).A); out['util/nd'] = npy(DB.nd(G2).A); out['util/t'] = npy(DB.t(G2).A)
+    out['util/v2d'] = npy(DB.v2d(DB.Batch(x1.clone(), n_nodes)).A); out['util/masked2'] = npy(G2.A)
+    for cfg in ('light', 'default'):
+        run(f'lin11_{cfg}', DLinear(1, 1, D, 5, cfg=cfg), 1)
+        run(f'lin12_{cfg}', DLinear(1, 2, D, 6, cfg=cfg), 1)
+        run(f'lin22_{cfg}', DLinear(2, 2, D, 7, cfg=cfg), 2)
+        run(f'lin21_{cfg}', DLinear(2, 1, D, 5, cfg=cfg), 2)
+    run('lin20', DLinear(2, 0, D, 4), 2)
+    run('lin10', DLinear(1, 0, D, 4), 1)
+    fm = lambda: KernelFeatureMap(dqk // H, generalized_attention=True)
+    run('att11', DAttn(1, 1, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
+    run('att12', DAttn(1, 2, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
+    enc = Encoder(1, 2, [1, 1], D, 3, 16, dqk, dv, dff, H, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
+    enc.skip_redraw_projections = True
+    run('enc', enc, 1)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dense':
+        dump_dense('dense_small.npz', [5, 3, 4], N=5, D=4, dqk=8, dv=8, H=2, dff=12, seed=81)
+        dump_dense('dense_c3.npz', [20, 20], N=20, D=2, dqk=32, dv=32, H=4, dff=32, seed=82)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'uniform':
         dump_uniform('uniform_small.npz', N=13, B=21, k=3, D=6, dqk=8, dv=8, H=2, seed=71)
         dump_uniform('uniform_gps.npz', N=221, B=400, k=3, D=16, dqk=32, dv=32, H=4, seed=72)

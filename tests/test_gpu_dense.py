@@ -1,0 +1,89 @@
+"""GPU (-m gpu): the dense layout (set input -> graph output) on the HIP kernels, through the
+DensePlan, against golden vectors captured from the reference's dense modules (tests/golden/make_golden.py dense):
+batch/dense.py helpers, models/dense/linear.py for every (ord_in, ord_out) in both cfgs, dense KernelSelfAttn 1->1 and
+1->2, and Encoder(1, 2, [1, 1], ..., sparse=False) as set-to-graph/main/models/model.py:9-30 builds it.  Outputs,
+masks (bit-exact) and gradients w.r.t. the input and every parameter."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, tt, rel_err
+from test_gpu_parity import _load_layer, _check_param_grads, TOL, DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize('name', ['dense_small.npz', 'dense_c3.npz'])
+def test_dense_layout_vs_reference(name):
+    from hot_amd.batch import dense as DB
+    from hot_amd.models.dense import Linear, KernelSelfAttn
+    from hot_amd.models.common import KernelFeatureMap
+    from hot_amd.models.encoder import Encoder
+    z = load_golden(name)
+    N, D, dqk, dv, H, dff = [int(v) for v in z['dims']]
+    n_nodes = [int(v) for v in z['n_nodes']]
+    x1, x2 = tt(z['x1']).to(DEV), tt(z['x2']).to(DEV)
+
+    G2 = DB.Batch(x2.clone(), n_nodes)
+    assert torch.equal(G2.A.cpu(), tt(z['util/masked2']))
+    assert torch.equal(DB.d(G2).A.cpu(), tt(z['util/d']))
+    assert torch.equal(DB.nd(G2).A.cpu(), tt(z['util/nd']))
+    assert torch.equal(DB.t(G2).A.cpu(), tt(z['util/t']))
+    assert torch.equal(DB.v2d(DB.Batch(x1.clone(), n_nodes)).A.cpu(), tt(z['util/v2d']))
+
+    def run(tag, mod, order):
+        mod = _load_layer(mod, z, tag)
+        x = (x1 if order == 1 else x2).clone().requires_grad_(True)
+        y = mod(DB.Batch(x, n_nodes))
+        ya = y if isinstance(y, torch.Tensor) else y.A
+        if not isinstance(y, torch.Tensor):
+            assert torch.equal(y.mask.cpu(), tt(z[f'{tag}/mask'])), tag
+        assert rel_err(ya.detach().cpu(), z[f'{tag}/y']) < TOL, tag
+        (ya * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
+        assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
+        _check_param_grads(mod, z, f'{tag}/grad/')
+
+    for cfg in ('light', 'default'):
+        run(f'lin11_{cfg}', Linear(1, 1, D, 5, cfg=cfg), 1)
+        run(f'lin12_{cfg}', Linear(1, 2, D, 6, cfg=cfg), 1)
+        if cfg == 'light':
+            run(f'lin22_{cfg}', Linear(2, 2, D, 7, cfg=cfg), 2)
+            run(f'lin21_{cfg}', Linear(2, 1, D, 5, cfg=cfg), 2)
+        else:
+            with pytest.raises(NotImplementedError):
+                Linear(2, 2, D, 7, cfg=cfg)
+    run('lin20', Linear(2, 0, D, 4), 2)
+    run('lin10', Linear(1, 0, D, 4), 1)
+    fm = lambda: KernelFeatureMap(dqk // H, generalized_attention=True)
+    run('att11', KernelSelfAttn(1, 1, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
+    run('att12', KernelSelfAttn(1, 2, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
+    enc = Encoder(1, 2, [1, 1], D, 3, 16, dqk, dv, dff, H, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
+    enc.skip_redraw_projections = True
+    run('enc', enc, 1)
+
+
+def test_dense_set_to_graph_c3_shape():
+    """C3 at its real size (Delaunay sets of 50 points, set-to-graph/main/main_delaunay.py): B = 16 sets, N = 50, the
+    EncoderS2G stack Encoder(1, 2, [1, 1, 1], 2 -> 64, sparse=False).  Size-independent properties: permuting the points
+    of a set permutes rows and columns of the output graph (equivariance), padding rows stay exact zeros, gradients are
+    finite (the reference's own integration tests assert shapes and finiteness only, tests/test_dense_attn.py)."""
+    from hot_amd.batch import dense as DB
+    from hot_amd.models.encoder import Encoder
+    torch.manual_seed(5)
+    B, N = 16, 50
+    enc = Encoder(1, 2, [1, 1, 1], 2, 8, 64, 32, 32, 64, 4, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0.,
+                  sparse=False).to(DEV)
+    enc.skip_redraw_projections = True
+    n_nodes = [N] * (B - 1) + [N - 7]
+    x = torch.randn(B, N, 2, device=DEV)
+    xg = x.clone().requires_grad_(True)
+    y = enc(DB.Batch(xg, n_nodes))
+    assert y.A.shape == (B, N, N, 8) and y.order == 2
+    assert float(y.A[-1, N - 7:].abs().max()) == 0.0 and float(y.A[-1, :, N - 7:].abs().max()) == 0.0
+    y.A.square().sum().backward()
+    assert torch.isfinite(xg.grad).all() and float(xg.grad.abs().max()) > 0
+    assert all(torch.isfinite(p_.grad).all() for p_ in enc.parameters())
+    perm = torch.randperm(N, device=DEV)
+    yp = enc(DB.Batch(x[:, perm].clone(), n_nodes[:-1] + [N])).A      # full sets only: a permutation moves padding
+    y0 = enc(DB.Batch(x.clone(), n_nodes[:-1] + [N])).A
+    assert rel_err(yp.detach().cpu(), y0[:, perm][:, :, perm].detach().cpu()) < 1e-4

@@ -89,3 +89,36 @@ def test_projection_matrix_construction():
     for blk in (P[:8], P[8:]):
         G = blk @ blk.t()
         assert torch.allclose(G - torch.diag(torch.diag(G)), torch.zeros(8, 8), atol=1e-4)
+
+
+def test_dense_plan_index_arrays_brute_force():
+    """DensePlan (the dense [B,N,N] layout read as the complete index set; batch/dense.py:47-54 masks) is pure index
+    bookkeeping and runs on the CPU: kinds, node rows, transposed rows, diagonal positions and both CSR views against
+    Python loops, on ragged sizes including an empty graph."""
+    import torch
+    from hot_amd.plan import DensePlan
+    n_nodes, N = [3, 0, 4, 1], 4
+    P = DensePlan(n_nodes, N, 'cpu')
+    assert (P.R, P.Nn, P.Emax, P.Nmax, P.Ev) == (4 * 16, 16, 16, 4, 9 + 0 + 16 + 1)
+    rows_of, cols_of = {}, {}
+    for b, n in enumerate(n_nodes):
+        for i in range(N):
+            node = b * N + i
+            assert int(P.nkind[node]) == (1 if i < n else 0)
+            assert int(P.diag_pos[node]) == ((b * N + i) * N + i if i < n else -1)
+            for j in range(N):
+                r = (b * N + i) * N + j
+                valid = i < n and j < n
+                assert int(P.kind[r]) == (0 if not valid else 1 if i == j else 2)
+                assert int(P.rown[r]) == (b * N + i if valid else -1)
+                assert int(P.coln[r]) == (b * N + j if valid else -1)
+                assert int(P.tpos[r]) == ((b * N + j) * N + i if valid else -1)
+                if valid:
+                    rows_of.setdefault(b * N + i, []).append(r)
+                    cols_of.setdefault(b * N + j, []).append(r)
+    for ptr, perm, ref in ((P.row_ptr, P.row_perm, rows_of), (P.col_ptr, P.col_perm, cols_of)):
+        for node in range(P.Nn):
+            seg = perm[int(ptr[node]):int(ptr[node + 1])].tolist()
+            assert seg == ref.get(node, []), node
+    assert P.g_nend.tolist() == [b * N + n for b, n in enumerate(n_nodes)]
+    assert P.n_entries_dev.tolist() == [n * n for n in n_nodes]
