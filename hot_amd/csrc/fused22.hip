@@ -1227,8 +1227,13 @@ bool core_valu() {
   return v != 0;
 }
 
+// rows of one graph per wave in the per-graph sum kernels: fewer, longer chunks mean fewer partial sums to write and
+// reduce (each partial is 4 x 9 x 64 floats)
+#ifndef HOTK_CHUNK_ROWS
+#define HOTK_CHUNK_ROWS 256
+#endif
 void chunking(int64_t Emax, int* cpg, int* rows) {
-  int64_t c = (Emax + 63) / 64;
+  int64_t c = (Emax + HOTK_CHUNK_ROWS - 1) / HOTK_CHUNK_ROWS;
   if (c > 4096) c = 4096;
   if (c < 1) c = 1;
   *cpg = (int)c;

@@ -3,5 +3,5 @@
 n=$1; shift
 for l in "$@"; do
   echo "== $l"
-  HOTK_LIB=$GRAFT_REPO_ROOT/$l scratch/kfused.sh ab_$(basename $l .so) $n | grep -E "entries|fwd|k_graphsum_fwd" || exit 1
+  HOTK_LIB=$GRAFT_REPO_ROOT/$l scratch/kfused.sh ab_$(basename $l .so) $n | grep -E "entries|k_graph" || exit 1
 done
