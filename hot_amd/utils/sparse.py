@@ -21,10 +21,11 @@ def get_transpose_info(indices: torch.LongTensor, mask: torch.BoolTensor, chunk_
 
 def do_transpose(values, transpose_indices, exist_mask, plan=None):
     """T[b,e] = values[b, t_indices[b,e]] * t_mask[b,e] (utils/sparse.py:130-134)."""
-    B, E = exist_mask.shape
     if plan is not None:
+        B, E = plan.B, plan.Emax
         tpos = plan.tpos
     else:
+        B, E = exist_mask.shape
         base = (torch.arange(B, device=values.device) * E)[:, None]
         tpos = torch.where(exist_mask, transpose_indices + base, torch.full_like(transpose_indices, -1))
         tpos = tpos.reshape(-1).to(torch.int32)

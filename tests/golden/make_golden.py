@@ -378,6 +378,20 @@ def dump_dense(name, n_nodes, N, D, dqk, dv, H, dff, seed):
     fm = lambda: KernelFeatureMap(dqk // H, generalized_attention=True)
     run('att11', DAttn(1, 1, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
     run('att12', DAttn(1, 2, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
+    run('att21', DAttn(2, 1, D, dv, dqk, H, 'default', 0., 0., fm()), 2)
+    run('att22', DAttn(2, 2, D, dv, dqk, H, 'default', 0., 0., fm()), 2)
+    enc22 = Encoder(2, 2, [2], D, 3, 16, dqk, dv, dff, H, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
+    enc22.skip_redraw_projections = True
+    run('enc22', enc22, 2)
+    # the same model and inputs in float64: how far the reference's own fp32 result is from the exact one
+    enc22.zero_grad(set_to_none=True)
+    e64 = enc22.double()
+    x64 = x2.double().clone().requires_grad_(True)
+    y64 = e64(DB.Batch(x64, n_nodes)).A
+    (y64 * torch.from_numpy(out['enc22/R']).double()).sum().backward()
+    out['enc22/f64/y'] = npy(y64); out['enc22/f64/gx'] = npy(x64.grad)
+    for k_, p in e64.named_parameters():
+        out[f'enc22/f64/grad/{k_}'] = npy(p.grad)
     enc = Encoder(1, 2, [1, 1], D, 3, 16, dqk, dv, dff, H, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
     enc.skip_redraw_projections = True
     run('enc', enc, 1)

@@ -57,6 +57,25 @@ def test_dense_layout_vs_reference(name):
     fm = lambda: KernelFeatureMap(dqk // H, generalized_attention=True)
     run('att11', KernelSelfAttn(1, 1, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
     run('att12', KernelSelfAttn(1, 2, D, dv, dqk, H, 'default', 0., 0., fm()), 1)
+    run('att21', KernelSelfAttn(2, 1, D, dv, dqk, H, 'default', 0., 0., fm()), 2)
+    run('att22', KernelSelfAttn(2, 2, D, dv, dqk, H, 'default', 0., 0., fm()), 2)
+    enc22 = Encoder(2, 2, [2], D, 3, 16, dqk, dv, dff, H, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
+    enc22.skip_redraw_projections = True
+    # Two LayerNorm'd 2->2 layers: at hidden width 16 (dense_small) the reference's OWN fp32 gradients are 6e-5 away
+    # from its float64 run (fixture enc22/f64/*), so fp32-vs-fp32 agreement at 2e-5 is not defined there.  Outputs are
+    # held to 1e-5 against the fp32 reference; gradients to the float64 run, no further from it than twice the
+    # reference's fp32 result is (and never looser than needed: 2e-5 floor).
+    mod = _load_layer(enc22, z, 'enc22')
+    x = x2.clone().requires_grad_(True)
+    y = mod(DB.Batch(x, n_nodes))
+    assert torch.equal(y.mask.cpu(), tt(z['enc22/mask']))
+    assert rel_err(y.A.detach().cpu(), z['enc22/y']) < TOL
+    (y.A * tt(z['enc22/R']).to(DEV)).sum().backward()
+    ref_gap = rel_err(z['enc22/gx'], z['enc22/f64/gx'])
+    assert rel_err(x.grad.cpu(), z['enc22/f64/gx']) < max(2 * TOL, 2 * ref_gap), ref_gap
+    for k, p_ in mod.named_parameters():
+        ref_gap = rel_err(z[f'enc22/grad/{k}'], z[f'enc22/f64/grad/{k}'])
+        assert rel_err(p_.grad.cpu(), z[f'enc22/f64/grad/{k}']) < max(2 * TOL, 2 * ref_gap), (k, ref_gap)
     enc = Encoder(1, 2, [1, 1], D, 3, 16, dqk, dv, dff, H, 0, 0, 0, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
     enc.skip_redraw_projections = True
     run('enc', enc, 1)
