@@ -32,11 +32,6 @@ def _order2_carrier(Sv: SB.Batch, values: torch.Tensor) -> SB.Batch:
 
 class Linear(_SparseLinear):
     def __init__(self, ord_in, ord_out, dim_in, dim_out, bias=True, cfg='default', normalize=True):
-        if cfg == 'default' and ord_in == 2 and ord_out in (1, 2):
-            # dense/linear.py:113-169 orders and pairs its pooled blocks differently from the sparse class; only the
-            # cases pinned by golden vectors are offered (the Encoder uses cfg='light' throughout, encoder.py:40-46,65)
-            raise NotImplementedError("dense Linear(2, %d, cfg='default') is not built; use cfg='light' or the sparse "
-                                      "layout" % ord_out)
         super().__init__(ord_in, ord_out, dim_in, dim_out, bias, cfg, normalize)
 
     def _1_to_2(self, Sv: SB.Batch) -> SB.Batch:
@@ -76,6 +71,18 @@ class Linear(_SparseLinear):
         if (w.ord_in, w.ord_out) == (1, 2):
             assert isinstance(Sv, SB.Batch) and Sv.order == 1
             return self._1_to_2(Sv)
+        if (w.ord_in, w.ord_out, w.cfg) == (2, 2, 'default'):
+            # the dense class lists the pooled column sums before the row sums (dense/linear.py:146-148, A6 / A7), the
+            # sparse one the other way round (sparse/linear.py:187-199): blocks 5 and 6 of the weight trade places
+            assert isinstance(Sv, SB.Batch) and Sv.order == 2
+            D = w.weight.size(0) // 15
+            W = torch.cat([w.weight[:5 * D], w.weight[6 * D:7 * D], w.weight[5 * D:6 * D], w.weight[7 * D:]], 0)
+            plan = Sv.plan
+            y = ops.RowsMatmul.apply(basis.basis_2_to_2(Sv, w.normalize), W, None)
+            bias = self.bias.bias if hasattr(self, 'bias') else None
+            y = ops.BiasMask.apply(y, plan.kind, None if bias is None else bias[0], None if bias is None else bias[1],
+                                   plan.Ev == plan.R)
+            return SB.batch_like(Sv, y.view(*Sv.values.shape[:-1], y.size(-1)), skip_masking=True)
         return _SparseLinear.forward(self, Sv)
 
     def forward(self, G: Union[DB.Batch, torch.Tensor]) -> Union[DB.Batch, torch.Tensor]:

@@ -46,12 +46,8 @@ def test_dense_layout_vs_reference(name):
     for cfg in ('light', 'default'):
         run(f'lin11_{cfg}', Linear(1, 1, D, 5, cfg=cfg), 1)
         run(f'lin12_{cfg}', Linear(1, 2, D, 6, cfg=cfg), 1)
-        if cfg == 'light':
-            run(f'lin22_{cfg}', Linear(2, 2, D, 7, cfg=cfg), 2)
-            run(f'lin21_{cfg}', Linear(2, 1, D, 5, cfg=cfg), 2)
-        else:
-            with pytest.raises(NotImplementedError):
-                Linear(2, 2, D, 7, cfg=cfg)
+        run(f'lin22_{cfg}', Linear(2, 2, D, 7, cfg=cfg), 2)
+        run(f'lin21_{cfg}', Linear(2, 1, D, 5, cfg=cfg), 2)
     run('lin20', Linear(2, 0, D, 4), 2)
     run('lin10', Linear(1, 0, D, 4), 1)
     fm = lambda: KernelFeatureMap(dqk // H, generalized_attention=True)
