@@ -2,23 +2,27 @@
 
 Same constructor, attribute names (`layers.<k>.weight.weight`, `layers.<k>.bias.bias.<j>`) and forward signature as
 hot_pytorch/models/mlp.py:15-40: every layer is `Linear(cfg='default', normalize=True)`, i.e. the full 15 / 5 / 2-operation
-basis, with a pointwise nonlinearity and dropout between layers.  Only the sparse layout is built here (the dense
-[B,N,N,D] layout is out of scope): `sparse=False` raises."""
+basis, with a pointwise nonlinearity and dropout between layers.  sparse=False takes the dense [B,N,N,D] layout
+(hot_amd/models/dense, the same kernels through the DensePlan)."""
 from typing import List, Union
 
 import torch.nn as nn
 
 from ..batch.sparse import Batch as S
-from .sparse.linear import Linear
-from .sparse.f import Nonlinear, Apply
+from ..batch.dense import Batch as D
+from .sparse.linear import Linear as S_Linear
+from .sparse.f import Nonlinear as S_Nonlinear, Apply as S_Apply
+from .dense.linear import Linear as D_Linear
+from .dense.f import Nonlinear as D_Nonlinear, Apply as D_Apply
 
 
 class MLP(nn.Module):
     def __init__(self, ord_in, ord_out, ord_hidden: list, dim_in, dim_out, dim_hidden: Union[List, int], f='relu', dropout=0.,
                  sparse=True):
         super().__init__()
-        if not sparse:
-            raise NotImplementedError('hot_amd builds the sparse layout only (dense [B,N,N,D] layers are out of scope)')
+        Linear = S_Linear if sparse else D_Linear
+        Nonlinear = S_Nonlinear if sparse else D_Nonlinear
+        Apply = S_Apply if sparse else D_Apply
         self.sparse = sparse
         if not isinstance(dim_hidden, list):
             dim_hidden = [dim_hidden] * len(ord_hidden)
@@ -33,6 +37,6 @@ class MLP(nn.Module):
                 layers.append(Apply(nn.Dropout(p=dropout)))
         self.layers = nn.Sequential(*layers)
 
-    def forward(self, G: S):
-        assert isinstance(G, S)
+    def forward(self, G: Union[S, D]):
+        assert isinstance(G, S if self.sparse else D)
         return self.layers(G)

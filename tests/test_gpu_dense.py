@@ -77,6 +77,24 @@ def test_dense_layout_vs_reference(name):
     run('enc', enc, 1)
 
 
+def test_dense_mlp_runs_and_is_equivariant():
+    """MLP(..., sparse=False) (models/mlp.py:15-40 with the dense classes): every layer is a dense Linear(cfg='default')
+    pinned one by one above; here the stack 2 -> 2 -> 1 -> 0 end to end: permutation invariance of the graph vector and
+    finite gradients."""
+    from hot_amd.batch import dense as DB
+    from hot_amd.models.mlp import MLP
+    torch.manual_seed(3)
+    mlp = MLP(2, 0, [2, 1], 4, 3, 8, 'relu', 0., sparse=False).to(DEV)
+    x = torch.randn(3, 6, 6, 4, device=DEV, requires_grad=True)
+    y = mlp(DB.Batch(x, [6, 6, 6]))
+    assert y.shape == (3, 3)
+    y.square().sum().backward()
+    assert torch.isfinite(x.grad).all() and float(x.grad.abs().max()) > 0
+    perm = torch.randperm(6, device=DEV)
+    yp = mlp(DB.Batch(x.detach()[:, perm][:, :, perm].clone(), [6, 6, 6]))
+    assert rel_err(yp.detach().cpu(), y.detach().cpu()) < 1e-5
+
+
 def test_dense_set_to_graph_c3_shape():
     """C3 at its real size (Delaunay sets of 50 points, set-to-graph/main/main_delaunay.py): B = 16 sets, N = 50, the
     EncoderS2G stack Encoder(1, 2, [1, 1, 1], 2 -> 64, sparse=False).  Size-independent properties: permuting the points
