@@ -7,8 +7,21 @@ from ... import ops
 from ..._lib import KEEP_DIAG, KEEP_OFFDIAG
 
 
+_COUNT_CACHE = {}
+
+
 def _counts(x, dtype, device):
-    return torch.as_tensor(x, dtype=dtype, device=device)
+    """python list of per-graph sizes -> device tensor, uploaded once per list object (a host-to-device copy per
+    forward would also forbid capturing the step into a HIP graph)"""
+    key = (id(x), len(x), dtype, str(device))
+    hit = _COUNT_CACHE.get(key)
+    if hit is not None and hit[0] is x:
+        return hit[1]
+    if len(_COUNT_CACHE) > 64:
+        _COUNT_CACHE.clear()
+    t = torch.as_tensor(x, dtype=dtype, device=device)
+    _COUNT_CACHE[key] = (x, t)
+    return t
 
 
 def _safe_div(x, cnt):
@@ -94,7 +107,7 @@ def basis_1_to_1(G, normalize):
     x = G.values.reshape(plan.Nn, -1)
     ng = plan_node_graph(plan)
     if normalize:
-        n1 = torch.as_tensor(G.n_nodes, dtype=x.dtype, device=x.device)[ng.long()].unsqueeze(1) - 1
+        n1 = _counts(G.n_nodes, x.dtype, x.device)[ng.long()].unsqueeze(1) - 1
         n1 = torch.where(n1 == 0, torch.full_like(n1, 1e-5), n1)
         x = x / n1
         xs = G.values.reshape(plan.Nn, -1)

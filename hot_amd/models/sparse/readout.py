@@ -40,9 +40,10 @@ class AvgPool(nn.Module):
     def forward(self, G: B) -> torch.Tensor:
         assert G.order == self.order
         dev = G.values.device
-        n = torch.tensor(G.n_nodes, device=dev)
+        from .basis import _counts
+        n = _counts(G.n_nodes, torch.long, dev)
         n_inv = (n + 1e-5).pow(-1).unsqueeze(1)
         if self.order == 1:
             return n_inv * _graph_sum(G, KEEP_VALID)
-        e_inv = (torch.tensor(G.n_edges, device=dev) - n + 1e-5).pow(-1).unsqueeze(1)
+        e_inv = (_counts(G.n_edges, torch.long, dev) - n + 1e-5).pow(-1).unsqueeze(1)
         return _graph_sum(G, KEEP_DIAG) * n_inv + _graph_sum(G, KEEP_OFFDIAG) * e_inv
