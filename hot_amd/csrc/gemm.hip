@@ -37,65 +37,94 @@ struct Epi {
   const float* b_diag;
 };
 
-// addends of one 32-column tile for this lane's row: 4 quads x (first, second) float4
+// The epilogue runs on a row-major image of the 32 x 32 result tile: the accumulators (lane pair = one row, 16 bytes
+// per quad) go through a wave-private LDS image and come back as lane = (row r = 8 i + (lane >> 3), float4 column
+// c4 = lane & 7), so every global access of the epilogue -- the result store, the gathered node rows, the residual --
+// is a full 128-byte row piece shared by 8 consecutive lanes.  (Stores straight from the accumulator layout are 32 rows
+// x 32 B per instruction; measured on the 10 M-row entry GEMM: 6.7 ms with them, 3.5 ms with stores and gathers
+// compiled out = the MFMA time.)
+constexpr int WAVES = 8;           // waves per workgroup, all sharing one LDS copy of the weight
+constexpr int OS = 36;             // floats per staged result row (32 + 4: conflict-free 16-byte writes)
+
+struct RowMeta {                   // epilogue operands of one result row (MODE 1) or its residual row (MODE 0)
+  const float* p1;
+  const float* p2;
+  const float* pb;
+  float m1, m2, mb;
+  bool live;
+};
+
+// addends of one 32-column tile for this lane's four rows
 struct Addend {
   float4 u[4], w[4];
 };
 
 template <int MODE>
-__device__ __forceinline__ void fetch_addend(Addend& ad, const Epi& ep, const float* p1, const float* p2, const float* pres,
-                                             int col0) {
-  // col0 = n0 + 32 t + 4 half: the lane's first column of the tile; quad q adds 8 q
+__device__ __forceinline__ void fetch_addend(Addend& ad, const RowMeta (&rm)[4], bool has_res, int col) {
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int i = 0; i < 4; ++i) {
     if (MODE == 1) {
-      ad.u[q] = *reinterpret_cast<const float4*>(p1 + col0 + 8 * q);
-      ad.w[q] = *reinterpret_cast<const float4*>(p2 + col0 + 8 * q);
-    } else if (pres) {
-      ad.u[q] = *reinterpret_cast<const float4*>(pres + col0 + 8 * q);
+      ad.u[i] = *reinterpret_cast<const float4*>(rm[i].p1 + col);
+      ad.w[i] = *reinterpret_cast<const float4*>(rm[i].p2 + col);
+    } else if (has_res) {
+      ad.u[i] = *reinterpret_cast<const float4*>(rm[i].p1 + col);
     }
   }
 }
 
+__device__ __forceinline__ void gemm_wave_fence() {
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int KH, int TG, int MODE>
-__global__ __launch_bounds__(256) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
-                                                   float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
-  extern __shared__ __align__(16) float w_lds[];   // [2 KH][C]
+__global__ __launch_bounds__(64 * WAVES) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                          float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
+  extern __shared__ __align__(16) float w_lds[];   // [2 KH][C], then WAVES x [32][OS] result images
   constexpr int K = 2 * KH;
   const int tid = threadIdx.x;
-  for (int i = tid * 4; i < K * C; i += 256 * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
+  for (int i = tid * 4; i < K * C; i += 64 * WAVES * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, half = lane >> 5;
-  const int64_t n_tiles = (R + 127) / 128;
+  float* img = w_lds + K * C + wave * 32 * OS;
+  const int er = lane >> 3, ec = 4 * (lane & 7);       // epilogue: rows 8 i + er, columns ec .. ec + 3 of a tile
+  const bool has_res = MODE == 0 && ep.res != nullptr;
+  const int64_t n_tiles = (R + 32 * WAVES - 1) / (32 * WAVES);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-    const int64_t row0 = tile * 128 + wave * 32;
+    const int64_t row0 = tile * (32 * WAVES) + wave * 32;
     if (row0 >= R) continue;
-    const bool live = row0 + j < R;
-    const int64_t row = live ? row0 + j : R - 1;      // rows past the end re-read the last row and store nothing
+    const int64_t row = row0 + j < R ? row0 + j : R - 1;      // rows past the end re-read the last row and store nothing
     // per-row epilogue operands: MODE 1 folds the three row kinds into two gathered rows, two multipliers and a bias
     // selector (x2 is zero on diagonal and padding rows, so the accumulator contributes nothing there):
     //   off-diagonal: acc + yn[i][C..) + yn[j][2C..) + b_off    diagonal: 0 + yn[v][0..) + 0 + b_diag    padding: 0
-    const float* p1 = nullptr;
-    const float* p2 = nullptr;
-    const float* pres = nullptr;
-    const float* pb = ep.bias;
-    float m1 = 0.f, m2 = 0.f, mb = pb ? 1.f : 0.f;
-    if (MODE == 1) {
-      const int kd = ep.kind[row];
-      // padding rows carry node id -1 (plan): they read node row 0 and multiply it by zero
-      const int32_t rn = ep.rown[row], cn = ep.coln[row];
-      const float* yi = ep.yn + (int64_t)(kd != 0 ? rn : 0) * ep.ld_yn;
-      const float* yj = ep.yn + (int64_t)(kd == 2 ? cn : 0) * ep.ld_yn;
-      p1 = kd == 2 ? yi + C : yi;
-      p2 = kd == 2 ? yj + 2 * C : yi;
-      m1 = kd != 0 ? 1.f : 0.f;
-      m2 = kd == 2 ? 1.f : 0.f;
-      pb = kd == 2 ? ep.b_off : ep.b_diag;
-      mb = (kd != 0 && pb) ? 1.f : 0.f;
-    } else if (ep.res) {
-      pres = ep.res + row * ep.ld_res;
+    RowMeta rm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t rr = row0 + 8 * i + er;
+      rm[i].live = rr < R;
+      const int64_t rc = rm[i].live ? rr : R - 1;
+      rm[i].p1 = rm[i].p2 = nullptr;
+      rm[i].pb = ep.bias;
+      rm[i].m1 = rm[i].m2 = 0.f;
+      rm[i].mb = ep.bias ? 1.f : 0.f;
+      if (MODE == 1) {
+        const int kd = ep.kind[rc];
+        // padding rows carry node id -1 (plan): they read node row 0 and multiply it by zero
+        const int32_t rn = ep.rown[rc], cn = ep.coln[rc];
+        const float* yi = ep.yn + (int64_t)(kd != 0 ? rn : 0) * ep.ld_yn;
+        const float* yj = ep.yn + (int64_t)(kd == 2 ? cn : 0) * ep.ld_yn;
+        rm[i].p1 = (kd == 2 ? yi + C : yi) + ec;
+        rm[i].p2 = (kd == 2 ? yj + 2 * C : yi) + ec;
+        rm[i].m1 = kd != 0 ? 1.f : 0.f;
+        rm[i].m2 = kd == 2 ? 1.f : 0.f;
+        rm[i].pb = kd == 2 ? ep.b_off : ep.b_diag;
+        rm[i].mb = (kd != 0 && rm[i].pb) ? 1.f : 0.f;
+      } else if (has_res) {
+        rm[i].p1 = ep.res + rc * ep.ld_res + ec;
+      }
+      if (!rm[i].pb) rm[i].pb = W;   // any readable address: multiplied by mb = 0
+      rm[i].pb += ec;
     }
-    if (!pb) pb = W;   // any readable address: multiplied by mb = 0
     const float* ap = A + row * lda + half * KH;
     float a[KH];
 #pragma unroll
@@ -104,9 +133,8 @@ __global__ __launch_bounds__(256) void k_thin_gemm(const float* __restrict__ A, 
       a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
     }
     const float* wl = w_lds + half * KH * C + j;
-    float* yr = Y + row * ldy + 4 * half;
     Addend cur, nxt;
-    fetch_addend<MODE>(cur, ep, p1, p2, pres, 4 * half);
+    fetch_addend<MODE>(cur, rm, has_res, 0);
     for (int n0 = 0; n0 < C; n0 += 32 * TG) {
       f32x16 acc[TG];
 #pragma unroll
@@ -125,23 +153,32 @@ __global__ __launch_bounds__(256) void k_thin_gemm(const float* __restrict__ A, 
       for (int t = 0; t < TG; ++t) {
         // request the next tile's addends (this group or the first tile of the next group) before finishing this one
         const int ncol = (t + 1 < TG) ? n0 + 32 * (t + 1) : n0 + 32 * TG;
-        if (ncol < C) fetch_addend<MODE>(nxt, ep, p1, p2, pres, ncol + 4 * half);
-        const int col0 = n0 + 32 * t + 4 * half;
+        if (ncol < C) fetch_addend<MODE>(nxt, rm, has_res, ncol);
+        const int col0 = n0 + 32 * t;
+        gemm_wave_fence();
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float4 bb = *reinterpret_cast<const float4*>(pb + col0 + 8 * q);
           float4 v;
           v.x = acc[t][4 * q + 0]; v.y = acc[t][4 * q + 1]; v.z = acc[t][4 * q + 2]; v.w = acc[t][4 * q + 3];
+          *reinterpret_cast<float4*>(img + j * OS + 8 * q + 4 * half) = v;
+        }
+        gemm_wave_fence();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float4 v = *reinterpret_cast<const float4*>(img + (8 * i + er) * OS + ec);
+          const float4 bb = *reinterpret_cast<const float4*>(rm[i].pb + col0);
+          const float mb = rm[i].mb;
           if (MODE == 1) {
-            v.x = fmaf(mb, bb.x, fmaf(m2, cur.w[q].x, fmaf(m1, cur.u[q].x, v.x)));
-            v.y = fmaf(mb, bb.y, fmaf(m2, cur.w[q].y, fmaf(m1, cur.u[q].y, v.y)));
-            v.z = fmaf(mb, bb.z, fmaf(m2, cur.w[q].z, fmaf(m1, cur.u[q].z, v.z)));
-            v.w = fmaf(mb, bb.w, fmaf(m2, cur.w[q].w, fmaf(m1, cur.u[q].w, v.w)));
+            const float m1 = rm[i].m1, m2 = rm[i].m2;
+            v.x = fmaf(mb, bb.x, fmaf(m2, cur.w[i].x, fmaf(m1, cur.u[i].x, v.x)));
+            v.y = fmaf(mb, bb.y, fmaf(m2, cur.w[i].y, fmaf(m1, cur.u[i].y, v.y)));
+            v.z = fmaf(mb, bb.z, fmaf(m2, cur.w[i].z, fmaf(m1, cur.u[i].z, v.z)));
+            v.w = fmaf(mb, bb.w, fmaf(m2, cur.w[i].w, fmaf(m1, cur.u[i].w, v.w)));
           } else {
             v.x = fmaf(mb, bb.x, v.x); v.y = fmaf(mb, bb.y, v.y); v.z = fmaf(mb, bb.z, v.z); v.w = fmaf(mb, bb.w, v.w);
-            if (pres) { v.x += cur.u[q].x; v.y += cur.u[q].y; v.z += cur.u[q].z; v.w += cur.u[q].w; }
+            if (has_res) { v.x += cur.u[i].x; v.y += cur.u[i].y; v.z += cur.u[i].z; v.w += cur.u[i].w; }
           }
-          if (live) *reinterpret_cast<float4*>(yr + n0 + 32 * t + 8 * q) = v;
+          if (rm[i].live) *reinterpret_cast<float4*>(Y + (row0 + 8 * i + er) * ldy + col0 + ec) = v;
         }
         cur = nxt;
       }
@@ -152,7 +189,7 @@ __global__ __launch_bounds__(256) void k_thin_gemm(const float* __restrict__ A, 
 template <int KH, int TG, int MODE>
 int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
            hipStream_t st) {
-  const size_t lds = (size_t)2 * KH * C * sizeof(float);
+  const size_t lds = ((size_t)2 * KH * C + (size_t)WAVES * 32 * OS) * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit of a kernel is a per-process property of the function
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
@@ -160,18 +197,21 @@ int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, i
       return HOTK_ELAUNCH;
     attr_set = true;
   }
-  const int64_t n_tiles = (R + 127) / 128;
-  // persistent workgroups: LDS (weight) allows two per CU at the C1 shapes
-  const int per_cu = lds <= 76 * 1024 ? 2 : 1;
+  const int64_t n_tiles = (R + 32 * WAVES - 1) / (32 * WAVES);
+  // persistent workgroups: two per CU where the weight and the result images allow it
+  const int per_cu = lds <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
-  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE>), dim3(grid), dim3(256), lds, st, A, lda, W, Y, ldy, R, C, ep);
+  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
   return hotk_launch_status();
 }
 
 template <int MODE>
 int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, float* Y, int64_t ldy, int64_t R,
              const Epi& ep, hipStream_t st) {
-  if (K == 64 && C % 96 == 0) return launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  // gathered addends (MODE 1) are requested one 32-column tile ahead: with one tile per MFMA loop their latency hides
+  // behind the whole loop
+  if (K == 64 && C % 96 == 0) return MODE == 1 ? launch<32, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st)
+                                               : launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 32 && C % 160 == 0) return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 288 && C % 64 == 0) return launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 320 && C % 32 == 0) return launch<160, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
@@ -181,7 +221,7 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
 bool shape_ok(int64_t K, int64_t C) {
   const bool known = (K == 64 && C % 96 == 0) || (K == 32 && C % 160 == 0) || (K == 288 && C % 64 == 0) ||
                      (K == 320 && C % 32 == 0);
-  return known && K * C * (int64_t)sizeof(float) <= 150 * 1024;
+  return known && (K * C + WAVES * 32 * OS) * (int64_t)sizeof(float) <= 150 * 1024;
 }
 
 }  // namespace

@@ -101,9 +101,16 @@ THIN_MIN_ROWS = 1 << 15
 
 def thin_ok(R, K, C):
     """the hand-written LDS-resident-weight MFMA GEMM (csrc/gemm.hip) covers this product.  It is used where an
-    epilogue is fused (entry GEMM + assembly of Linear(2,2,'light'): 6.7 ms vs 5.4 + 5.8 ms; fc_o + bias + skip path);
-    for plain products it runs on par with the library GEMM (3.0-4.6 TB/s of row traffic either way), which stays."""
+    epilogue is fused (entry GEMM + assembly of Linear(2,2,'light'): 6.2 ms vs 5.4 + 5.8 ms; fc_o + bias + skip path)
+    and for the narrow-to-wide plain products (thin_wide_ok); elsewhere it runs on par with the library GEMM, which
+    stays."""
     return R >= THIN_MIN_ROWS and lib().hotk_thin_gemm_supported(int(K), int(C)) == 1
+
+
+def thin_wide_ok(R, K, C):
+    """narrow-to-wide product [R, 32] x [32, 320] (fc_v, d att = d y . W_o): the result store dominates and the
+    row-major staged epilogue of csrc/gemm.hip writes full 128-byte row pieces: 4.15 ms vs 4.64 ms (library) at 10 M rows"""
+    return K == 32 and C >= 8 * K and thin_ok(R, K, C)
 
 
 def thin_gemm(A, W, bias=None, res=None):
@@ -561,6 +568,8 @@ class RowsMatmul(Function):
         ctx.has_b = b is not None
         x2 = x.reshape(-1, x.size(-1))
         # 2-D result on purpose (a fresh tensor, not a view): callers may finish it in place (BiasMask)
+        if x2.is_cuda and x2.dtype == torch.float32 and thin_wide_ok(x2.size(0), x2.size(1), w.size(1)):
+            return thin_gemm(x2.contiguous(), w, b)
         return torch.addmm(b, x2, w) if b is not None else x2 @ w
 
     @staticmethod
@@ -660,7 +669,7 @@ class AttnCore22(Function):
         d_out = d_out.contiguous().view(plan.R, D)
         padded = plan.Ev != plan.R
         dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
-        datt = dy @ w_o
+        datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else dy @ w_o
         dw_o = wgrad(dy, att)
         db_o = dy.sum(0)
         padded = plan.Ev != plan.R
