@@ -3,7 +3,7 @@
 Tensors are torch tensors (device memory, streams: plumbing); all arithmetic on the path happens in the HIP
 kernels.  Each wrapper states which reference code it stands in for.
 """
-from ctypes import byref, c_size_t, c_float
+from ctypes import byref, c_size_t, c_float, c_int64 as ctypes_long
 
 import torch
 from torch.autograd import Function
@@ -111,6 +111,20 @@ def thin_wide_ok(R, K, C):
     """narrow-to-wide product [R, 32] x [32, 320] (fc_v, d att = d y . W_o): the result store dominates and the
     row-major staged epilogue of csrc/gemm.hip writes full 128-byte row pieces: 4.15 ms vs 4.64 ms (library) at 10 M rows"""
     return K == 32 and C >= 8 * K and thin_ok(R, K, C)
+
+
+def linear_bwd_fused(g, x, w):
+    """(dx [R,K], dW [K,C], db [C]) of y = x @ w + b from g = dy [R,C] in one pass (hotk_linear_bwd_fused); the per-wave
+    partial blocks are summed in a fixed order (deterministic)"""
+    R, C = g.shape
+    K = x.size(1)
+    n = ctypes_long()
+    check(lib().hotk_linear_bwd_partials(R, byref(n)), 'hotk_linear_bwd_partials')
+    part = torch.empty(n.value, K + 2, C, dtype=g.dtype, device=g.device)
+    dx = torch.empty(R, K, dtype=g.dtype, device=g.device)
+    call('hotk_linear_bwd_fused', 4 * R * (C + 2 * K), p(g), C, p(x), K, p(w.contiguous()), K, C, p(dx), K, p(part), R)
+    tot = part.sum(0)
+    return dx, tot[:K], tot[K] + tot[K + 1]
 
 
 def thin_gemm(A, W, bias=None, res=None):
@@ -577,9 +591,15 @@ class RowsMatmul(Function):
         x, w = ctx.saved_tensors
         g2 = g.reshape(-1, g.size(-1))
         x2 = x.reshape(-1, x.size(-1))
+        want_b = ctx.has_b and ctx.needs_input_grad[2]
+        if (g2.is_cuda and g2.dtype == torch.float32 and ctx.needs_input_grad[0] and ctx.needs_input_grad[1]
+                and g2.size(0) >= THIN_MIN_ROWS and lib().hotk_linear_bwd_supported(x2.size(1), g2.size(1)) == 1):
+            # narrow input, wide gradient: dx, dW and db from ONE pass over g (csrc/linbwd.hip) instead of a data-gradient
+            # GEMM, a split-K batched GEMM over [x | 1] and the concatenation that builds it
+            dx, dw, db = linear_bwd_fused(g2.contiguous(), x2.contiguous(), w)
+            return dx.view(x.shape), dw, (db if want_b else None)
         dx = (g2 @ w.t()).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = db = None
-        want_b = ctx.has_b and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1] and want_b and g2.size(1) > 2 * x2.size(1) and x2.size(0) >= (1 << 16):
             # g is the wide operand: [x | 1]^T @ g yields dW and db in ONE pass over g
             xa = torch.cat([x2, torch.ones(x2.size(0), 1, dtype=x2.dtype, device=x2.device)], dim=1)

@@ -210,6 +210,17 @@ int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int6
                               int64_t ld_out, const float* dout, int64_t ld_dout, float* dq, int64_t ld_dq, float* dk,
                               int64_t ld_dk, float* dv, int64_t ld_dv, int64_t n_seg, int H, int d, int c, void* stream);
 
+/* Backward of a narrow-input linear layer y[R, C] = x[R, K] @ W[K, C] + b in one pass over g = dy [R, C]
+ * (nn.Linear fc_v of models/sparse/kernelattn.py:51,65-68 under autograd; the reference gets the three gradients from
+ * aten's addmm backward):  dx[R, K] = g @ W^T;  partial[n][K + 2][C]: per-wave partial sums of x^T @ g (rows 0..K-1)
+ * and of the column sums of g (rows K, K + 1).  The caller sums the n = hotk_linear_bwd_partials(R) blocks in order:
+ * dW = sum[0:K], db = sum[K] + sum[K + 1].  Shapes: K = 32 and C in {64, 320} (hotk_linear_bwd_supported), others
+ * HOTK_EUNSUPPORTED.  g, x, dx rows 16-byte aligned. */
+int hotk_linear_bwd_supported(int64_t K, int64_t C);
+int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);
+int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K, int64_t C,
+                          float* dx, int64_t lddx, float* partial, int64_t R, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused attention core of KernelSelfAttn(2,2) (models/sparse/kernelattn.py:119-159): all ten kernel-attention
  * terms from the raw projections, for the shape 4 heads x 16 features (one wavefront per slot), head width 8,

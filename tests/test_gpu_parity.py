@@ -324,6 +324,35 @@ def test_thin_gemm_vs_fp64(K, C):
         assert rel_err(y0.cpu(), (A.double() @ W.double()).float().cpu()) < TOL
 
 
+@pytest.mark.parametrize('R,C', [(70001, 320), (33000, 64), (255, 320)])
+def test_linear_bwd_fused_vs_fp64(R, C):
+    """hotk_linear_bwd_fused (csrc/linbwd.hip): dx, dW and db of y = x @ W + b from one pass over dy, against fp64
+    products; row counts that are not a multiple of the 256-row workgroup tile (and one below a single tile), padded
+    leading dimensions are exercised through the module path below."""
+    _lib, ops, *_ = _product()
+    torch.manual_seed(R + C)
+    K = 32
+    g = torch.randn(R, C, device=DEV)
+    x = torch.randn(R, K, device=DEV)
+    w = torch.randn(K, C, device=DEV)
+    dx, dw, db = ops.linear_bwd_fused(g, x, w)
+    gd, xd, wd = g.double(), x.double(), w.double()
+    assert rel_err(dx.cpu(), (gd @ wd.t()).cpu()) < TOL
+    assert rel_err(dw.cpu(), (xd.t() @ gd).cpu()) < TOL
+    assert rel_err(db.cpu(), gd.sum(0).cpu()) < TOL
+    # the autograd path of the projection (RowsMatmul) takes the fused kernel for this shape and the library otherwise
+    if R >= ops.THIN_MIN_ROWS:
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        b = torch.randn(C, device=DEV, requires_grad=True)
+        y = ops.RowsMatmul.apply(xr, wr, b)
+        assert rel_err(y.detach().cpu(), (xd @ wd + b.detach().double()).cpu()) < TOL
+        (y * g).sum().backward()
+        assert rel_err(xr.grad.cpu(), (gd @ wd.t()).cpu()) < TOL
+        assert rel_err(wr.grad.cpu(), (xd.t() @ gd).cpu()) < TOL
+        assert rel_err(b.grad.cpu(), gd.sum(0).cpu()) < TOL
+
+
 def test_linear22_entry_gemm_matches_assemble_path():
     """entry GEMM of the factored Linear(2,2,'light') with the fused assembly epilogue (hotk_linear22_entry_fwd) against
     the library GEMM + hotk_assemble22 path, on ragged graphs (padding rows, one-directional edges), incl. gradients"""
