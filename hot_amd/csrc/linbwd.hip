@@ -29,7 +29,7 @@ __device__ __forceinline__ void lb_fence() {
 }
 
 // columns [c_lo, c_lo + 32 NCH) of g / W; Ctot = full width (row stride of W and of the partial blocks)
-template <int NCH>
+template <int NCH, bool WANT_DX>
 __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
                                                              int64_t ldx, const float* __restrict__ W, float* __restrict__ DX,
                                                              int64_t lddx, float* __restrict__ partial, int64_t R, int c_lo,
@@ -41,8 +41,10 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, half = lane >> 5;
   float* gt = lds + LB_K * CS + wave * (32 * LB_GS + 32 * LB_OS);   // staged g chunk [32][GS]
   float* xt = gt + 32 * LB_GS;                                        // staged x tile / dx image [32][OS]
-  for (int i = tid; i < LB_K * C; i += 64 * LB_WAVES) w_lds[(i / C) * CS + (i % C)] = W[(i / C) * Ctot + c_lo + (i % C)];
-  __syncthreads();
+  if (WANT_DX) {
+    for (int i = tid; i < LB_K * C; i += 64 * LB_WAVES) w_lds[(i / C) * CS + (i % C)] = W[(i / C) * Ctot + c_lo + (i % C)];
+    __syncthreads();
+  }
   f32x16 dw[NCH];
   float dbp[NCH];
 #pragma unroll
@@ -102,10 +104,13 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
         const float gb = gt[(2 * s + half) * LB_GS + j];     // g[row 2s + half][c = j]
         dw[ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], gb, dw[ch], 0, 0, 0);
         dbp[ch] += gb;
-        const float gr = gt[j * LB_GS + 2 * s + half];        // g[row j][c = 2s + half]
-        dxa = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[2 * s], gr, dxa, 0, 0, 0);
+        if (WANT_DX) {
+          const float gr = gt[j * LB_GS + 2 * s + half];      // g[row j][c = 2s + half]
+          dxa = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[2 * s], gr, dxa, 0, 0, 0);
+        }
       }
     }
+    if (!WANT_DX) continue;
     // dx: lane (row j, half) owns k = 8 q + 4 half + (0..3); through the LDS image to full 128-byte row stores
     lb_fence();
 #pragma unroll
@@ -140,18 +145,18 @@ unsigned lb_grid(int64_t R) {
   return (unsigned)(n_tiles < 256 ? (n_tiles < 1 ? 1 : n_tiles) : 256);
 }
 
-template <int NCH>
+template <int NCH, bool WANT_DX>
 int lb_launch(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
               float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
   constexpr int C = 32 * NCH;
   const size_t lds = ((size_t)LB_K * (C + 2) + (size_t)LB_WAVES * (32 * LB_GS + 32 * LB_OS)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_linear_bwd<NCH>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_linear_bwd<NCH, WANT_DX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_linear_bwd<NCH>), dim3(lb_grid(R)), dim3(64 * LB_WAVES), lds, st, G, ldg, X, ldx, W, DX, lddx, partial, R,
+  hipLaunchKernelGGL((k_linear_bwd<NCH, WANT_DX>), dim3(lb_grid(R)), dim3(64 * LB_WAVES), lds, st, G, ldg, X, ldx, W, DX, lddx, partial, R,
                      c_lo, Ctot, add_dx);
   return hotk_launch_status();
 }
@@ -168,19 +173,27 @@ extern "C" int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials) {
 
 extern "C" int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K,
                                      int64_t C, float* dx, int64_t lddx, float* partial, int64_t R, void* stream) {
-  HOTK_CHECK_ARG(R >= 0 && ldg >= C && ldx >= K && lddx >= K);
+  HOTK_CHECK_ARG(R >= 0 && ldg >= C && ldx >= K && (!dx || lddx >= K));
   if (!hotk_linear_bwd_supported(K, C)) return HOTK_EUNSUPPORTED;
-  HOTK_CHECK_ARG(g && x && W && dx && partial);
-  HOTK_CHECK_ARG(hotk_aligned16(g) && hotk_aligned16(x) && hotk_aligned16(dx) && ((ldg | ldx | lddx) & 3) == 0);
+  HOTK_CHECK_ARG(g && x && partial && (!dx || W));
+  HOTK_CHECK_ARG(hotk_aligned16(g) && hotk_aligned16(x) && (!dx || hotk_aligned16(dx)) && ((ldg | ldx) & 3) == 0 &&
+                 (!dx || (lddx & 3) == 0));
   if (R == 0) {
     // the caller sums lb_grid(0) * WAVES partial blocks: give it zeros
     return hipMemsetAsync(partial, 0, (size_t)LB_WAVES * (LB_K + 2) * C * sizeof(float), (hipStream_t)stream) == hipSuccess
                ? HOTK_OK : HOTK_ELAUNCH;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (C == 320) {
-    const int rc = lb_launch<5>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 320, 0, st);
-    return rc ? rc : lb_launch<5>(g, ldg, x, ldx, W, dx, lddx, partial, R, 160, 320, 1, st);
+  if (!dx) {   // weight / bias gradients only (W is not read)
+    if (C == 320) {
+      const int rc = lb_launch<5, false>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 320, 0, st);
+      return rc ? rc : lb_launch<5, false>(g, ldg, x, ldx, W, dx, lddx, partial, R, 160, 320, 0, st);
+    }
+    return lb_launch<2, false>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 64, 0, st);
   }
-  return lb_launch<2>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 64, 0, st);
+  if (C == 320) {
+    const int rc = lb_launch<5, true>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 320, 0, st);
+    return rc ? rc : lb_launch<5, true>(g, ldg, x, ldx, W, dx, lddx, partial, R, 160, 320, 1, st);
+  }
+  return lb_launch<2, true>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 64, 0, st);
 }

@@ -214,7 +214,8 @@ int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int6
  * (nn.Linear fc_v of models/sparse/kernelattn.py:51,65-68 under autograd; the reference gets the three gradients from
  * aten's addmm backward):  dx[R, K] = g @ W^T;  partial[n][K + 2][C]: per-wave partial sums of x^T @ g (rows 0..K-1)
  * and of the column sums of g (rows K, K + 1).  The caller sums the n = hotk_linear_bwd_partials(R) blocks in order:
- * dW = sum[0:K], db = sum[K] + sum[K + 1].  Shapes: K = 32 and C in {64, 320} (hotk_linear_bwd_supported), others
+ * dW = sum[0:K], db = sum[K] + sum[K + 1].  dx = NULL: only the partial sums (W is not read) -- the weight gradient of a
+ * wide-INPUT layer y = a @ W^T is the same product with x := dy and g := a (fc_o, kernelattn.py:52).  Shapes: K = 32 and C in {64, 320} (hotk_linear_bwd_supported), others
  * HOTK_EUNSUPPORTED.  g, x, dx rows 16-byte aligned. */
 int hotk_linear_bwd_supported(int64_t K, int64_t C);
 int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);

@@ -340,6 +340,8 @@ def test_linear_bwd_fused_vs_fp64(R, C):
     assert rel_err(dx.cpu(), (gd @ wd.t()).cpu()) < TOL
     assert rel_err(dw.cpu(), (xd.t() @ gd).cpu()) < TOL
     assert rel_err(db.cpu(), gd.sum(0).cpu()) < TOL
+    none, dw2, db2 = ops.linear_bwd_fused(g, x, None)          # weight / bias gradients only
+    assert none is None and torch.equal(dw2, dw) and torch.equal(db2, db)
     # the autograd path of the projection (RowsMatmul) takes the fused kernel for this shape and the library otherwise
     if R >= ops.THIN_MIN_ROWS:
         xr = x.clone().requires_grad_(True)
