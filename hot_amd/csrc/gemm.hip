@@ -23,6 +23,9 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef HOTK_ENTRY_WAVES
+#define HOTK_ENTRY_WAVES 8   /* measured at 10 M rows: 4 waves 7.9 ms, 8 waves 6.1 ms, 16 waves (128 VGPRs, spills) 6.7 ms */
+#endif
 
 struct Epi {
   const float* bias;      // MODE 0: [C] or null
@@ -43,15 +46,13 @@ struct Epi {
 // is a full 128-byte row piece shared by 8 consecutive lanes.  (Stores straight from the accumulator layout are 32 rows
 // x 32 B per instruction; measured on the 10 M-row entry GEMM: 6.7 ms with them, 3.5 ms with stores and gathers
 // compiled out = the MFMA time.)
-constexpr int WAVES = 8;           // waves per workgroup, all sharing one LDS copy of the weight
+constexpr int MAX_WAVES = 16;      // waves per workgroup (template parameter NW), all sharing one LDS copy of the weight
 constexpr int OS = 36;             // floats per staged result row (32 + 4: conflict-free 16-byte writes)
 
-struct RowMeta {                   // epilogue operands of one result row (MODE 1) or its residual row (MODE 0)
-  const float* p1;
-  const float* p2;
-  const float* pb;
-  float m1, m2, mb;
-  bool live;
+struct RowMeta {                   // epilogue operands of one result row, kept small (the kernel runs at 128 VGPRs):
+  uint32_t o1, o2;                 // MODE 1: element offsets into the node table yn (host checks Nn * ld_yn < 2^32)
+  int kd;                          // MODE 1: row kind (0 padding, 1 diagonal, 2 off-diagonal); MODE 0: 1 = row exists
+  const float* pres;               // MODE 0: residual row or null
 };
 
 // addends of one 32-column tile for this lane's four rows
@@ -60,14 +61,15 @@ struct Addend {
 };
 
 template <int MODE>
-__device__ __forceinline__ void fetch_addend(Addend& ad, const RowMeta (&rm)[4], bool has_res, int col) {
+__device__ __forceinline__ void fetch_addend(Addend& ad, const RowMeta (&rm)[4], const float* __restrict__ yn, bool has_res,
+                                             int col) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     if (MODE == 1) {
-      ad.u[i] = *reinterpret_cast<const float4*>(rm[i].p1 + col);
-      ad.w[i] = *reinterpret_cast<const float4*>(rm[i].p2 + col);
+      ad.u[i] = *reinterpret_cast<const float4*>(yn + rm[i].o1 + col);
+      ad.w[i] = *reinterpret_cast<const float4*>(yn + rm[i].o2 + col);
     } else if (has_res) {
-      ad.u[i] = *reinterpret_cast<const float4*>(rm[i].p1 + col);
+      ad.u[i] = *reinterpret_cast<const float4*>(rm[i].pres + col);
     }
   }
 }
@@ -77,10 +79,11 @@ __device__ __forceinline__ void gemm_wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int KH, int TG, int MODE>
-__global__ __launch_bounds__(64 * WAVES) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+template <int KH, int TG, int MODE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                           float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
-  extern __shared__ __align__(16) float w_lds[];   // [2 KH][C], then WAVES x [32][OS] result images
+  constexpr int WAVES = NW;
+  extern __shared__ __align__(16) float w_lds[];   // [2 KH][C], then NW x [32][OS] result images
   constexpr int K = 2 * KH;
   const int tid = threadIdx.x;
   for (int i = tid * 4; i < K * C; i += 64 * WAVES * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
@@ -101,30 +104,25 @@ __global__ __launch_bounds__(64 * WAVES) void k_thin_gemm(const float* __restric
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t rr = row0 + 8 * i + er;
-      rm[i].live = rr < R;
-      const int64_t rc = rm[i].live ? rr : R - 1;
-      rm[i].p1 = rm[i].p2 = nullptr;
-      rm[i].pb = ep.bias;
-      rm[i].m1 = rm[i].m2 = 0.f;
-      rm[i].mb = ep.bias ? 1.f : 0.f;
+      const bool live = rr < R;
+      const int64_t rc = live ? rr : R - 1;
+      rm[i].o1 = rm[i].o2 = 0;
+      rm[i].kd = live ? 1 : 0;
+      rm[i].pres = nullptr;
       if (MODE == 1) {
         const int kd = ep.kind[rc];
         // padding rows carry node id -1 (plan): they read node row 0 and multiply it by zero
         const int32_t rn = ep.rown[rc], cn = ep.coln[rc];
-        const float* yi = ep.yn + (int64_t)(kd != 0 ? rn : 0) * ep.ld_yn;
-        const float* yj = ep.yn + (int64_t)(kd == 2 ? cn : 0) * ep.ld_yn;
-        rm[i].p1 = (kd == 2 ? yi + C : yi) + ec;
-        rm[i].p2 = (kd == 2 ? yj + 2 * C : yi) + ec;
-        rm[i].m1 = kd != 0 ? 1.f : 0.f;
-        rm[i].m2 = kd == 2 ? 1.f : 0.f;
-        rm[i].pb = kd == 2 ? ep.b_off : ep.b_diag;
-        rm[i].mb = (kd != 0 && rm[i].pb) ? 1.f : 0.f;
+        const uint32_t yi = (uint32_t)(kd != 0 ? rn : 0) * (uint32_t)ep.ld_yn;
+        const uint32_t yj = (uint32_t)(kd == 2 ? cn : 0) * (uint32_t)ep.ld_yn;
+        rm[i].o1 = (kd == 2 ? yi + C : yi) + ec;
+        rm[i].o2 = (kd == 2 ? yj + 2 * C : yi) + ec;
+        rm[i].kd = live ? kd : -1;            // -1: past the end (nothing stored)
       } else if (has_res) {
-        rm[i].p1 = ep.res + rc * ep.ld_res + ec;
+        rm[i].pres = ep.res + rc * ep.ld_res + ec;
       }
-      if (!rm[i].pb) rm[i].pb = W;   // any readable address: multiplied by mb = 0
-      rm[i].pb += ec;
     }
+    const float* pb_any = (MODE == 1 ? (ep.b_off ? ep.b_off : (ep.b_diag ? ep.b_diag : W)) : (ep.bias ? ep.bias : W)) + ec;
     const float* ap = A + row * lda + half * KH;
     float a[KH];
 #pragma unroll
@@ -133,9 +131,12 @@ __global__ __launch_bounds__(64 * WAVES) void k_thin_gemm(const float* __restric
       a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
     }
     const float* wl = w_lds + half * KH * C + j;
+    // addends: TG == 1 requests a tile's addends in front of its own MFMA loop (one buffer); TG > 1 requests them one
+    // tile ahead (two buffers)
     Addend cur, nxt;
-    fetch_addend<MODE>(cur, rm, has_res, 0);
+    if (TG > 1) fetch_addend<MODE>(cur, rm, ep.yn, has_res, 0);
     for (int n0 = 0; n0 < C; n0 += 32 * TG) {
+      if (TG == 1) fetch_addend<MODE>(cur, rm, ep.yn, has_res, n0);
       f32x16 acc[TG];
 #pragma unroll
       for (int t = 0; t < TG; ++t)
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(64 * WAVES) void k_thin_gemm(const float* __restric
       for (int t = 0; t < TG; ++t) {
         // request the next tile's addends (this group or the first tile of the next group) before finishing this one
         const int ncol = (t + 1 < TG) ? n0 + 32 * (t + 1) : n0 + 32 * TG;
-        if (ncol < C) fetch_addend<MODE>(nxt, rm, has_res, ncol);
+        if (TG > 1 && ncol < C) fetch_addend<MODE>(nxt, rm, ep.yn, has_res, ncol);
         const int col0 = n0 + 32 * t;
         gemm_wave_fence();
 #pragma unroll
@@ -166,33 +167,39 @@ __global__ __launch_bounds__(64 * WAVES) void k_thin_gemm(const float* __restric
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float4 v = *reinterpret_cast<const float4*>(img + (8 * i + er) * OS + ec);
-          const float4 bb = *reinterpret_cast<const float4*>(rm[i].pb + col0);
-          const float mb = rm[i].mb;
+          const int kd = rm[i].kd;
           if (MODE == 1) {
-            const float m1 = rm[i].m1, m2 = rm[i].m2;
+            const float* pb = kd == 2 ? ep.b_off : ep.b_diag;
+            const float mb = (kd > 0 && pb) ? 1.f : 0.f;
+            const float4 bb = *reinterpret_cast<const float4*>((pb ? pb + ec : pb_any) + col0);
+            const float m1 = kd > 0 ? 1.f : 0.f, m2 = kd == 2 ? 1.f : 0.f;
             v.x = fmaf(mb, bb.x, fmaf(m2, cur.w[i].x, fmaf(m1, cur.u[i].x, v.x)));
             v.y = fmaf(mb, bb.y, fmaf(m2, cur.w[i].y, fmaf(m1, cur.u[i].y, v.y)));
             v.z = fmaf(mb, bb.z, fmaf(m2, cur.w[i].z, fmaf(m1, cur.u[i].z, v.z)));
             v.w = fmaf(mb, bb.w, fmaf(m2, cur.w[i].w, fmaf(m1, cur.u[i].w, v.w)));
           } else {
-            v.x = fmaf(mb, bb.x, v.x); v.y = fmaf(mb, bb.y, v.y); v.z = fmaf(mb, bb.z, v.z); v.w = fmaf(mb, bb.w, v.w);
+            if (ep.bias) {
+              const float4 bb = *reinterpret_cast<const float4*>(pb_any + col0);
+              v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+            }
             if (has_res) { v.x += cur.u[i].x; v.y += cur.u[i].y; v.z += cur.u[i].z; v.w += cur.u[i].w; }
           }
-          if (rm[i].live) *reinterpret_cast<float4*>(Y + (row0 + 8 * i + er) * ldy + col0 + ec) = v;
+          if (MODE == 1 ? kd >= 0 : kd != 0) *reinterpret_cast<float4*>(Y + (row0 + 8 * i + er) * ldy + col0 + ec) = v;
         }
-        cur = nxt;
+        if (TG > 1) cur = nxt;
       }
     }
   }
 }
 
-template <int KH, int TG, int MODE>
+template <int KH, int TG, int MODE, int NW = 8>
 int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
            hipStream_t st) {
+  constexpr int WAVES = NW;
   const size_t lds = ((size_t)2 * KH * C + (size_t)WAVES * 32 * OS) * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit of a kernel is a per-process property of the function
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
@@ -201,7 +208,7 @@ int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, i
   // persistent workgroups: two per CU where the weight and the result images allow it
   const int per_cu = lds <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
-  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
+  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
   return hotk_launch_status();
 }
 
@@ -210,7 +217,7 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
              const Epi& ep, hipStream_t st) {
   // gathered addends (MODE 1) are requested one 32-column tile ahead: with one tile per MFMA loop their latency hides
   // behind the whole loop
-  if (K == 64 && C % 96 == 0) return MODE == 1 ? launch<32, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st)
+  if (K == 64 && C % 96 == 0) return MODE == 1 ? launch<32, 1, MODE, HOTK_ENTRY_WAVES>(A, lda, W, Y, ldy, R, (int)C, ep, st)
                                                : launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 32 && C % 160 == 0) return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 288 && C % 64 == 0) return launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
@@ -221,7 +228,7 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
 bool shape_ok(int64_t K, int64_t C) {
   const bool known = (K == 64 && C % 96 == 0) || (K == 32 && C % 160 == 0) || (K == 288 && C % 64 == 0) ||
                      (K == 320 && C % 32 == 0);
-  return known && (K * C + WAVES * 32 * OS) * (int64_t)sizeof(float) <= 150 * 1024;
+  return known && (K * C + MAX_WAVES * 32 * OS) * (int64_t)sizeof(float) <= 150 * 1024;
 }
 
 }  // namespace
@@ -244,13 +251,15 @@ extern "C" int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, 
 extern "C" int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
                                        int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
                                        const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R,
-                                       void* stream) {
+                                       int64_t Nn, void* stream) {
   HOTK_CHECK_ARG(R >= 0 && K > 0 && C > 0 && ld_x2 >= K && ldy >= C && ld_yn >= 3 * C);
   if (!shape_ok(K, C)) return HOTK_EUNSUPPORTED;
   if (R == 0) return HOTK_OK;
   HOTK_CHECK_ARG(x2 && W && Y && yn && kind && rown && coln && hotk_aligned16(x2) && hotk_aligned16(W) && (ld_x2 & 3) == 0);
   HOTK_CHECK_ARG(hotk_aligned16(Y) && (ldy & 3) == 0 && hotk_aligned16(yn) && (ld_yn & 3) == 0 && (C & 3) == 0 &&
                  (!b_off || hotk_aligned16(b_off)) && (!b_diag || hotk_aligned16(b_diag)));
+  // node-table rows (Nn of them) are addressed with 32-bit element offsets
+  if (Nn < 0 || Nn * ld_yn >= ((int64_t)1 << 32)) return HOTK_EUNSUPPORTED;
   Epi ep{};
   ep.yn = yn; ep.ld_yn = ld_yn; ep.kind = kind; ep.rown = rown; ep.coln = coln; ep.b_off = b_off; ep.b_diag = b_diag;
   return dispatch<1>(x2, ld_x2, W, K, C, Y, ldy, R, ep, (hipStream_t)stream);

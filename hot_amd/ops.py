@@ -335,11 +335,11 @@ class Linear22Light(Function):
         yn = xd @ Wn
         x2 = torch.empty(plan.R, 2 * D, dtype=x.dtype, device=dev)
         call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
-        if thin_ok(n, 2 * D, C):
+        if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
             # entry GEMM with the assembly as its epilogue: y is written once
             y = torch.empty(n, C, dtype=x.dtype, device=dev)
             call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
-                 p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n)
+                 p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
         else:
             y = x2 @ W[D:3 * D]
             call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),

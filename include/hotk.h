@@ -130,13 +130,14 @@ int hotk_assemble22(float* z, int64_t ld, const float* yn, int64_t ld_yn, const 
  * and C a multiple of {160, 96, 64, 32} resp. (the C1 layer), K*C*4 <= 150 KB; hotk_thin_gemm_supported tells, other
  * shapes return HOTK_EUNSUPPORTED (the Python layer then uses the library GEMM).  A rows 16-byte aligned.
  * hotk_linear22_entry_fwd is the entry GEMM of the factored Linear(2,2,'light') with hotk_assemble22's epilogue applied
- * to the accumulators (one pass over Y instead of three). */
+ * to the accumulators (one pass over Y instead of three); Nn = rows of the node table yn (Nn * ld_yn < 2^32, else
+ * HOTK_EUNSUPPORTED: the caller then runs the library GEMM followed by hotk_assemble22). */
 int hotk_thin_gemm_supported(int64_t K, int64_t C);
 int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
                         const float* res, int64_t ld_res, float* Y, int64_t ldy, int64_t R, void* stream);
 int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
                             int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
-                            const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R, void* stream);
+                            const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R, int64_t Nn, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K2  FAVOR+ random-feature maps (models/common/kernel.py:81-138 fused with the head split, loop mask

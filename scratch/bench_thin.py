@@ -35,5 +35,5 @@ n, D, Cc = plan.R, 32, 288
 x2 = torch.randn(n, 2 * D, device=dev); W = torch.randn(2 * D, Cc, device=dev); yn = torch.randn(plan.Nn, 3 * Cc, device=dev)
 bo = torch.randn(Cc, device=dev); bd = torch.randn(Cc, device=dev); y = torch.empty(n, Cc, device=dev)
 t = timeit(lambda: call('hotk_linear22_entry_fwd', 0, p(x2), 2 * D, p(W), 2 * D, Cc, p(yn), 3 * Cc, p(plan.kind), p(plan.rown),
-                        p(plan.coln), p(bo), p(bd), p(y), Cc, n))
+                        p(plan.coln), p(bo), p(bd), p(y), Cc, n, plan.Nn))
 print(f'entry GEMM + assembly ({n} rows): {t:6.3f} ms ({4.0 * n * (2 * D + Cc) / 1e9 / t:5.2f} TB/s)')
