@@ -59,23 +59,27 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd_8x16(const float* 
   float pr[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) pr[k] = proj[mm * 8 + k];
-  const int64_t F = (int64_t)HH * 16, total = n * F;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t r = t / F;
-    const int f = (int)(t - r * F);
-    const int hh = f >> 4;
-    float o = 0.f;
-    if (!kind || hotk_keep(keep, kind[r])) {
-      const float4 a = *reinterpret_cast<const float4*>(x + r * ld_x + hh * 8);
-      const float4 b = *reinterpret_cast<const float4*>(x + r * ld_x + hh * 8 + 4);
-      float s = 0.f;
-      s = fmaf(a.x * scale, pr[0], s); s = fmaf(a.y * scale, pr[1], s);
-      s = fmaf(a.z * scale, pr[2], s); s = fmaf(a.w * scale, pr[3], s);
-      s = fmaf(b.x * scale, pr[4], s); s = fmaf(b.y * scale, pr[5], s);
-      s = fmaf(b.z * scale, pr[6], s); s = fmaf(b.w * scale, pr[7], s);
-      o = fmaxf(s, 0.f) + eps;
+  // a block walks whole rows (no 64-bit division per element): f = threadIdx.x, + blockDim.x, ... keeps mm = f & 15
+  const int F = HH * 16;
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const bool on = !kind || hotk_keep(keep, kind[r]);
+    const float* xr = x + r * ld_x;
+    float* pr_out = phi + r * ld_phi;
+    for (int f = threadIdx.x; f < F; f += PHI_THREADS) {
+      const int hh = f >> 4;
+      float o = 0.f;
+      if (on) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + hh * 8);
+        const float4 b = *reinterpret_cast<const float4*>(xr + hh * 8 + 4);
+        float s = 0.f;
+        s = fmaf(a.x * scale, pr[0], s); s = fmaf(a.y * scale, pr[1], s);
+        s = fmaf(a.z * scale, pr[2], s); s = fmaf(a.w * scale, pr[3], s);
+        s = fmaf(b.x * scale, pr[4], s); s = fmaf(b.y * scale, pr[5], s);
+        s = fmaf(b.z * scale, pr[6], s); s = fmaf(b.w * scale, pr[7], s);
+        o = fmaxf(s, 0.f) + eps;
+      }
+      pr_out[f] = o;
     }
-    phi[r * ld_phi + f] = o;
   }
 }
 
@@ -323,7 +327,7 @@ extern "C" int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, con
   hipStream_t st = (hipStream_t)stream;
   const float scale = powf((float)d, -0.25f);
   if (mode == HOTK_PHI_RELU && d == 8 && m == 16 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0) {
-    hipLaunchKernelGGL(k_phi_relu_fwd_8x16, dim3(hotk_grid(n * HH * m, PHI_THREADS, 256 * 32)), dim3(PHI_THREADS), 0, st, x,
+    hipLaunchKernelGGL(k_phi_relu_fwd_8x16, dim3(hotk_grid(n, 1, 256 * 32)), dim3(PHI_THREADS), 0, st, x,
                        ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
   } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_fwd, dim3(hotk_grid(n * HH * m, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
