@@ -793,8 +793,11 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
 // ------------------------------------------------------------------------------------------------
 // node segments (backward): one wave per (node, part), same split as the forward
 // ------------------------------------------------------------------------------------------------
+#ifndef HOTK_SEGB_WAVES
+#define HOTK_SEGB_WAVES 4
+#endif
 template <int P>
-__global__ __launch_bounds__(TPB) void k_seg_bwd(A a) {
+__global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const LaneB L = make_lane_b(a.proj);
@@ -1149,7 +1152,10 @@ __global__ __launch_bounds__(TPB, 4) void k_segt_fwd(A a) {
 // and off-diagonal rows (entry queries q2 slots 4, 5 against kvg slots 2, 3 -> terms 9, 10); also zero-fills the terms
 // that do not exist on a row kind (1, 2, 7, 8 off the diagonal; 3..6, 9, 10 on it).
 constexpr int GA_TILES = 8;   // 16-row tiles per wave
-__global__ __launch_bounds__(TPB, 4) void k_graph_apply_fwd_t(A a) {
+#ifndef HOTK_GA_WAVES
+#define HOTK_GA_WAVES 4
+#endif
+__global__ __launch_bounds__(TPB, HOTK_GA_WAVES) void k_graph_apply_fwd_t(A a) {
   __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
   float* tile = tile_all[threadIdx.x >> 6];
   const LaneT L = make_lane_t(a.proj);
