@@ -264,8 +264,8 @@ def test_mlp_default_basis_vs_reference(name):
         (yv * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
         assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
         _check_param_grads(mlp, z, f'{tag}/grad/')
-    with pytest.raises(NotImplementedError):
-        MLP(2, 2, [2], D, 5, 7, sparse=False)
+    # the dense variant is built from the dense classes (tests/test_gpu_dense.py)
+    assert MLP(2, 2, [2], D, 5, 7, sparse=False).sparse is False
 
 
 @pytest.mark.parametrize('name', ['uniform_small.npz', 'uniform_gps.npz'])
