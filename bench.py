@@ -32,7 +32,7 @@ BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEAD
 # HBM traffic of the fused core per valid entry on THIS workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
 # profiles/r01_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at 2 M entries (per-entry figures are size-independent)
-PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4902, 'hotk_attn22_backward': 8643}
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4903, 'hotk_attn22_backward': 8584}
 
 
 def build_structure(n_graphs, distinct=512, seed=1234):
