@@ -66,13 +66,19 @@ class Attn22Args(ctypes.Structure):
                  ('att', _P), ('ld_att', _L), ('kvg', _P),
                  ('datt', _P), ('ld_datt', _L), ('dout', _P), ('ld_dout', _L),
                  ('dh1', _P), ('ld_dh1', _L), ('dh2', _P), ('ld_dh2', _L), ('dv', _P), ('ld_dv', _L),
-                 ('ck', _P), ('dkvg', _P)])
+                 ('ck', _P), ('dkvg', _P),
+                 ('kvn', _P), ('dkvn', _P), ('diag_w', ctypes.c_float)])
+
+
+# phases of hotk_attn22_phase (include/hotk.h)
+ATTN22_FWD_GRAPHSUM, ATTN22_FWD_NODESUM, ATTN22_FWD_APPLY, ATTN22_BWD_QUERY, ATTN22_BWD_KEYVAL = range(5)
 
 
 _SIGNATURES.update({
     'hotk_attn22_workspace_bytes': [_L, _L, ctypes.POINTER(_S)],
     'hotk_attn22_forward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
     'hotk_attn22_backward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
+    'hotk_attn22_phase': [ctypes.POINTER(Attn22Args), c_int, _P, _S, _P],
 })
 EXPORTS = sorted(list(_SIGNATURES) + ['hotk_strerror', 'hotk_version'])
 

@@ -274,6 +274,20 @@ __device__ __forceinline__ void kv_bwd_phi(const LaneB& L, float phi, const floa
   if (L.x < DH) dk[L.h * DH + L.x] = d;
 }
 
+// the same for an entry that enters the column sum with weight w (split-phase mode: the replicated diagonal entry)
+__device__ __forceinline__ void kv_bwd_phi_w(const LaneB& L, float phi, float w, const float (&val)[NC],
+                                             const float (&dkv)[NC + 1], const float (&drot)[NM], float* __restrict__ dv,
+                                             float* __restrict__ dk) {
+  float dphi = dkv[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
+  const float dvv = rot_dot(phi * w, drot);
+  if (dv && L.x < NC) dv[L.h * NC + L.x] = dvv;
+  const float dpre = phi > PHI_EPS ? dphi * w : 0.f;
+  const float d = rot_dot(dpre, L.pr);
+  if (L.x < DH) dk[L.h * DH + L.x] = d;
+}
+
 __device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
   for (int i = L.lane; i < nslots * SLOT; i += 64) p[i] = 0.f;
 }
@@ -526,8 +540,9 @@ __device__ __forceinline__ void load_kv3(const Lane& L, const A& a, int32_t e, i
   r[2] = a.v[rowoff(row < 0 ? e : row, a.ld_v) + 2 * P * SLOT + L.lane];
 }
 
-// per_entry(e, te, phi0, phi1): the two value slices are staged at stage[0..32) and stage[32..64)
-template <int P, class F>
+// per_entry(e, te, phi0, phi1, w): the two value slices are staged at stage[0..32) and stage[32..64); w is the weight of
+// the entry in the column sums: 1, or a.diag_w for the diagonal entry in split-phase (edge-shard) mode (W)
+template <int P, bool W = false, class F>
 __device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float* stage, int32_t n, F per_entry) {
   const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
   for (int32_t base = c0; base < c1; base += 64) {
@@ -537,17 +552,18 @@ __device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float
     auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
       const float rv[1] = {r[2]};
       stage_put<1>(L, stage, rv);
-      per_entry(rl(cb.e, k), rl(cb.te, k), r[0], r[1]);
+      per_entry(rl(cb.e, k), rl(cb.te, k), r[0], r[1], (W && rl(cb.kd, k) == 1) ? a.diag_w : 1.f);
     };
     pipeline4<3>(cnt, load, use);
   }
 }
 
-template <int P>
+template <int P, bool W = false>
 __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float* stage, int32_t n, float (&kv)[2][NC + 1]) {
   kv_zero<2>(kv);
-  for_col_entries<P>(L, a, stage, n, [&](int32_t, int32_t te, float phi0, float phi1) __attribute__((always_inline)) {
+  for_col_entries<P, W>(L, a, stage, n, [&](int32_t, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
     float val[8];
+    if (W) { phi0 *= w; phi1 *= w; }   // weights values and normaliser alike
     const float ts = te < 0 ? 0.f : 1.f;   // the transposed-value slot is slot 0 for P == 2, slot 1 otherwise
     slice8(L, stage + 0 * SLOT, val);
     if (P == 2) kv_acc_scaled(kv[0], phi0, val, ts);
@@ -558,7 +574,29 @@ __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float*
   });
 }
 
-template <int P, bool GT = true>   // GT: also the per-graph terms and the zero fill (false: k_graph_apply_fwd_t does them)
+// split-phase mode: the two sums of (node n, part P) in memory, [9][64] floats each, feature-major like part_store
+constexpr int64_t KVN_SLOT = (NC + 1) * 64;
+template <int P>
+__device__ __forceinline__ float* kvn_slot(float* base, int64_t n, int s) { return base + ((n * 3 + P) * 2 + s) * KVN_SLOT; }
+
+// phase FWD_NODESUM: the weighted local column sums of every valid node, for the caller to all-reduce
+template <int P>
+__global__ __launch_bounds__(TPB) void k_seg_kvsum(A a) {
+  __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
+  const Lane L = make_lane(a.proj);
+  float* stage = stage_all[threadIdx.x >> 6];
+  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+    if (!a.nkind[n]) continue;
+    float kv[2][NC + 1];
+    seg_accumulate<P, true>(L, a, stage, (int32_t)n, kv);
+    part_store(L, kvn_slot<P>(a.kvn, n, 0), kv[0]);
+    part_store(L, kvn_slot<P>(a.kvn, n, 1), kv[1]);
+  }
+}
+
+// GT: also the per-graph terms and the zero fill (false: k_graph_apply_fwd_t does them)
+// LOADKV: the node's sums come from a.kvn (split-phase mode) instead of being accumulated here
+template <int P, bool GT = true, bool LOADKV = false>
 __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
@@ -570,7 +608,12 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
     float rot0[NM], rot1[NM];
     {
       float kv[2][NC + 1];
-      seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+      if (LOADKV) {
+        kvg_load(L, kvn_slot<P>(a.kvn, n, 0), kv[0]);
+        kvg_load(L, kvn_slot<P>(a.kvn, n, 1), kv[1]);
+      } else {
+        seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+      }
       kv_to_rot<false>(L, kvbuf, kv[0], rot0);
       kv_to_rot<false>(L, kvbuf, kv[1], rot1);
     }
@@ -597,8 +640,10 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
       // entries of column n: terms 3, 5 (this node's sums) and 9, 10 (graph sums)
       const int64_t b = n / a.Nmax;
       float g0[NM], g1[NM];
-      kvg_load_rot(L, kvg_slot(a.kvg, b, 2), g0);
-      kvg_load_rot(L, kvg_slot(a.kvg, b, 3), g1);
+      if (GT) {
+        kvg_load_rot(L, kvg_slot(a.kvg, b, 2), g0);
+        kvg_load_rot(L, kvg_slot(a.kvg, b, 3), g1);
+      }
       const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
       for (int32_t base = c0; base < c1; base += 64) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
@@ -615,10 +660,12 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
           float x[8];
           slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 2 * SLOT);
           slice8(L, stage + 1 * SLOT, x); apply_fwd(L, x, rot1, o + 4 * SLOT);
-          slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 8 * SLOT);
-          slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 9 * SLOT);
-          o[L.lane] = 0.f;                 // terms 1, 2 live on the diagonal only
-          o[6 * SLOT + L.lane] = 0.f;      // terms 7, 8 too
+          if (GT) {
+            slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 8 * SLOT);
+            slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 9 * SLOT);
+            o[L.lane] = 0.f;                 // terms 1, 2 live on the diagonal only
+            o[6 * SLOT + L.lane] = 0.f;      // terms 7, 8 too
+          }
         };
         pipeline4<2>(cnt, load, use);
       }
@@ -796,7 +843,9 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
 #ifndef HOTK_SEGB_WAVES
 #define HOTK_SEGB_WAVES 4
 #endif
-template <int P>
+// MODE 0: the whole backward of a (node, part).  Split-phase mode: MODE 1 = query side only (the node's sums come from
+// a.kvn, d(sums) go to a.dkvn for the caller to all-reduce), MODE 2 = key / value side only (d(sums) from a.dkvn)
+template <int P, int MODE = 0>
 __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
@@ -807,10 +856,18 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
   for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float dkv[2][NC + 1];
-    kv_zero<2>(dkv);
-    {
+    if (MODE == 2) {
+      kvg_load(L, kvn_slot<P>(a.dkvn, n, 0), dkv[0]);
+      kvg_load(L, kvn_slot<P>(a.dkvn, n, 1), dkv[1]);
+    } else {
+      kv_zero<2>(dkv);
       float kv[2][NC + 1];
-      seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+      if (MODE == 1) {
+        kvg_load(L, kvn_slot<P>(a.kvn, n, 0), kv[0]);
+        kvg_load(L, kvn_slot<P>(a.kvn, n, 1), kv[1]);
+      } else {
+        seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+      }
       if (P == 0) {  // node queries (terms 1, 2)
         const int64_t dr = a.diag_pos[n];
         float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[rowoff((int32_t)dr, a.ld_datt) + L.lane]};
@@ -863,12 +920,17 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
         }
       }
     }
+    if (MODE == 1) {
+      part_store(L, kvn_slot<P>(a.dkvn, n, 0), dkv[0]);
+      part_store(L, kvn_slot<P>(a.dkvn, n, 1), dkv[1]);
+      continue;
+    }
     // key / value side of this part's two column sums: dV of the plain slot goes to row e, dV of the transposed
     // slot to row te; d(raw key) contributions go to ck[e] (summed per row node afterwards)
     float drot0[NM], drot1[NM];
     kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
     kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
-    for_col_entries<P>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1) __attribute__((always_inline)) {
+    for_col_entries<P, MODE == 2>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
       float* dve = a.dv + rowoff(e, a.ld_dv);
       float* dvt = te >= 0 ? a.dv + rowoff(te, a.ld_dv) : nullptr;
       float* ck = a.ck + rowoff(e, 6 * SLOT) + 2 * P * SLOT;
@@ -881,13 +943,15 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      kv_bwd_phi(L, phi0, val, dkv[0], drot0, d0, ck);
+      if (MODE == 2) kv_bwd_phi_w(L, phi0, w, val, dkv[0], drot0, d0, ck);
+      else kv_bwd_phi(L, phi0, val, dkv[0], drot0, d0, ck);
       slice8(L, stage + 1 * SLOT, val);
       if (P != 2 && te < 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      kv_bwd_phi(L, phi1, val, dkv[1], drot1, d1, ck + SLOT);
+      if (MODE == 2) kv_bwd_phi_w(L, phi1, w, val, dkv[1], drot1, d1, ck + SLOT);
+      else kv_bwd_phi(L, phi1, val, dkv[1], drot1, d1, ck + SLOT);
       if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
     });
   }
@@ -1314,5 +1378,71 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_seg_bwd<0>, gseg, dim3(TPB), 0, st, *a);
+  return hotk_launch_status();
+}
+
+// The core in phases for one graph sharded by entries (include/hotk.h): the caller all-reduces kvg / kvn after the
+// sum phases and dkvg / dkvn after BWD_QUERY.  Node-segment application runs on the VALU/DPP kernels (their sums are
+// feature-major in memory, as the all-reduce leaves them); the streaming per-graph kernels are shared with the
+// single-device path.
+extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(phase >= HOTK_ATTN22_FWD_GRAPHSUM && phase <= HOTK_ATTN22_BWD_KEYVAL);
+  HOTK_CHECK_ARG(a->kvg && a->kvn && hotk_aligned16(a->kvn) && a->diag_w > 0.f);
+  if (a->R == 0 || a->Nn == 0) return HOTK_OK;
+  hipStream_t st = (hipStream_t)stream;
+  int cpg, rows;
+  chunking(a->Emax, &cpg, &rows);
+  size_t need;
+  hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
+  float* part = (float*)workspace;
+  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
+  const dim3 gchunk(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP));
+  const dim3 gred(hotk_grid(a->B * 4, 1, 256 * 16));
+  switch (phase) {
+    case HOTK_ATTN22_FWD_GRAPHSUM:
+      if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
+      hipLaunchKernelGGL(k_graphsum_fwd, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
+      hipLaunchKernelGGL(k_graph_reduce, gred, dim3(256), 0, st, part, a->kvg, a->B, cpg, 0);
+      break;
+    case HOTK_ATTN22_FWD_NODESUM:
+      hipLaunchKernelGGL(k_seg_kvsum<0>, gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL(k_seg_kvsum<1>, gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL(k_seg_kvsum<2>, gseg, dim3(TPB), 0, st, *a);
+      break;
+    case HOTK_ATTN22_FWD_APPLY: {
+      HOTK_CHECK_ARG(a->att && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
+      const int64_t per = 16 * GA_TILES;
+      const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
+      hipLaunchKernelGGL(k_graph_apply_fwd_t, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL((k_seg_fwd<1, false, true>), gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL((k_seg_fwd<2, false, true>), gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL((k_seg_fwd<0, false, true>), gseg, dim3(TPB), 0, st, *a);
+      break;
+    }
+    case HOTK_ATTN22_BWD_QUERY:
+    case HOTK_ATTN22_BWD_KEYVAL:
+      HOTK_CHECK_ARG(a->dkvn && hotk_aligned16(a->dkvn) && a->datt && a->dh1 && a->dh2 && a->dv && a->ck && a->dkvg);
+      HOTK_CHECK_ARG(a->ld_datt >= 10 * SLOT && a->ld_dh1 >= 12 * SLOT && a->ld_dh2 >= 8 * SLOT + a->D && a->D >= 0 &&
+                     a->ld_dv >= 10 * SLOT);
+      HOTK_CHECK_ARG(((a->ld_datt | a->ld_dh1 | a->ld_dh2 | a->ld_dv) & 3) == 0 && hotk_aligned16(a->datt));
+      HOTK_CHECK_ARG(!a->dout || a->ld_dout >= a->D);
+      if (phase == HOTK_ATTN22_BWD_QUERY) {
+        if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
+        hipLaunchKernelGGL(k_graph_apply_bwd, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
+        hipLaunchKernelGGL(k_graph_reduce, gred, dim3(256), 0, st, part, a->dkvg, a->B, cpg, 1);
+        hipLaunchKernelGGL((k_seg_bwd<1, 1>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<2, 1>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<0, 1>), gseg, dim3(TPB), 0, st, *a);
+      } else {
+        hipLaunchKernelGGL(k_graphsum_bwd<true>, dim3(hotk_grid(a->B * ((a->Nmax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL(k_graphsum_bwd<false>, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<1, 2>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<2, 2>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<0, 2>), gseg, dim3(TPB), 0, st, *a);
+      }
+      break;
+  }
   return hotk_launch_status();
 }

@@ -117,7 +117,7 @@ class KernelSelfAttn(nn.Module):
     def _2_to_2(self, G: B):
         h_1 = self.fc_1(G)                      # [B, N, 12 dqk]: 4 query slots, 8 key slots
         h_2 = self.fc_2(G)                      # [B, |E|, 8 dqk + D]: 6 query slots, 2 key slots, skip path
-        if self._fused_ok() and getattr(G.plan, 'shard', None) is None:   # edge-shard mode all-reduces materialised sums
+        if self._fused_ok():   # (edge-shard mode: ops.AttnCore22 runs the core in phases with all-reduces in between)
             # padding rows are ignored by the kernels: no masking pass
             v = ops.RowsMatmul.apply(G.values, self.fc_v.weight.t(), self.fc_v.bias)   # [R, 10 dv]
             out = ops.AttnCore22.apply(h_1.values, h_2.values, v, self.feature_map.feature_map.projection_matrix,

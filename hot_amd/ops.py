@@ -671,8 +671,21 @@ class AttnCore22(Function):
         a.phik, a.ld_phik = phik.data_ptr(), 512
         a.att, a.ld_att, a.kvg = att.data_ptr(), 320, kvg.data_ptr()
         ws, nws = AttnCore22._workspace(plan, dev)
-        call('hotk_attn22_forward', 4 * plan.Ev * (8 * 32 + 10 * 32 + 10 * 32) + 4 * plan.Nn * 384,
-             byref(a), p(ws), nws)
+        shard = getattr(plan, 'shard', None)
+        kvn = None
+        if shard is None:
+            call('hotk_attn22_forward', 4 * plan.Ev * (8 * 32 + 10 * 32 + 10 * 32) + 4 * plan.Nn * 384,
+                 byref(a), p(ws), nws)
+        else:
+            # edge-shard mode (hot_amd.dist): the sums over ENTRIES are partial on a rank; the core runs in phases and
+            # the sums are all-reduced in between (per-graph sums of entry keys = kvg slots 1, 3; all per-node sums)
+            kvn = (torch.empty if plan.B == 1 else torch.zeros)(plan.Nn, 3 * 2 * 9 * 64, dtype=torch.float32, device=dev)
+            a.kvn, a.diag_w = kvn.data_ptr(), 1.0 / shard.world
+            AttnCore22._phase(a, _lib.ATTN22_FWD_GRAPHSUM, ws, nws, 4 * plan.Ev * 4 * 32)
+            AttnCore22._reduce_entry_slots(shard, kvg)
+            AttnCore22._phase(a, _lib.ATTN22_FWD_NODESUM, ws, nws, 4 * plan.Ev * 6 * 32 + 4 * kvn.numel())
+            shard.all_reduce_(kvn)
+            AttnCore22._phase(a, _lib.ATTN22_FWD_APPLY, ws, nws, 4 * plan.Ev * (6 * 32 + 10 * 32) + 4 * kvn.numel())
         skip = h2.view(plan.R, -1)[:, 256:]
         if not padded and thin_ok(plan.R, 320, D):
             out = thin_gemm(att, w_o.t(), b_o, skip).view(*h2.shape[:-1], D)      # projection + bias + skip path in one pass
@@ -681,13 +694,25 @@ class AttnCore22(Function):
             if padded:
                 y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
             out = y.add_(skip).view(*h2.shape[:-1], D)
-        ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg, phik)
+        ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg, phik, kvn)
         ctx.plan = plan
         return out
 
     @staticmethod
+    def _phase(a, phase, ws, nws, alg_bytes):
+        call('hotk_attn22_phase', alg_bytes, byref(a), phase, p(ws), nws)
+
+    @staticmethod
+    def _reduce_entry_slots(shard, kvg):
+        """per-graph sums whose keys are entries (terms 8, 10 = slots 1, 3) are partial on a rank; the node-keyed
+        slots 0, 2 are replicated work.  The rotated copies inside a slot are linear in it, so they reduce along."""
+        t = kvg[:, 1::2].contiguous()
+        shard.all_reduce_(t)
+        kvg[:, 1::2] = t
+
+    @staticmethod
     def backward(ctx, d_out):
-        h1, h2, v, proj, w_o, att, kvg, phik = ctx.saved_tensors
+        h1, h2, v, proj, w_o, att, kvg, phik, kvn = ctx.saved_tensors
         plan = ctx.plan
         dev = h2.device
         D = w_o.size(0)
@@ -717,8 +742,18 @@ class AttnCore22(Function):
         a.dv, a.ld_dv = dv.data_ptr(), 320
         a.ck, a.dkvg = ck.data_ptr(), dkvg.data_ptr()
         ws, nws = AttnCore22._workspace(plan, dev)
-        call('hotk_attn22_backward', 4 * plan.Ev * (8 * 32 * 2 + 10 * 32 * 3 + 6 * 32) + 4 * plan.Nn * 384 * 2,
-             byref(a), p(ws), nws)
+        shard = getattr(plan, 'shard', None)
+        if shard is None:
+            call('hotk_attn22_backward', 4 * plan.Ev * (8 * 32 * 2 + 10 * 32 * 3 + 6 * 32) + 4 * plan.Nn * 384 * 2,
+                 byref(a), p(ws), nws)
+        else:
+            # backward of the forward all-reduces: every rank needs the full d(sums) before its key / value side
+            dkvn = (torch.empty_like if plan.B == 1 else torch.zeros_like)(kvn)
+            a.kvn, a.dkvn, a.diag_w = kvn.data_ptr(), dkvn.data_ptr(), 1.0 / shard.world
+            AttnCore22._phase(a, _lib.ATTN22_BWD_QUERY, ws, nws, 4 * plan.Ev * (6 * 32 * 2 + 10 * 32) + 8 * kvn.numel())
+            AttnCore22._reduce_entry_slots(shard, dkvg)
+            shard.all_reduce_(dkvn)
+            AttnCore22._phase(a, _lib.ATTN22_BWD_KEYVAL, ws, nws, 4 * plan.Ev * (10 * 32 * 2 + 8 * 32 + 2 * 32) + 4 * kvn.numel())
         # d(raw key slots 0..5 of node i) = sum over the entries of row i of their per-entry contributions
         beg, end, perm, maxlen = plan.row_seg()
         if maxlen > SEG_CHUNK:

@@ -262,10 +262,29 @@ typedef struct hotk_attn22_args {
   float* dv; int64_t ld_dv;
   float* ck;
   float* dkvg;
+  /* split-phase (edge-shard) mode only, see hotk_attn22_phase; ignored by hotk_attn22_forward / _backward */
+  float* kvn;   /* [Nn][3 parts][2 slots][9][64] per-node key-value sums (feature-major, as the 9 first kvg channels) */
+  float* dkvn;  /* same shape: their gradients */
+  float diag_w; /* weight of a diagonal entry in the per-node sums (1/world: every rank holds all diagonal entries) */
 } hotk_attn22_args;
 int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes);
 int hotk_attn22_forward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
 int hotk_attn22_backward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
+
+/* The same core in phases, for ONE graph whose entries are sharded over ranks (SURVEY 8e edge-shard; the reference has
+ * no multi-device form of kernelattncoef.py:103-175, the sums are what its coalesce() builds on one device).  Sums over
+ * ENTRIES are partial on a rank: the caller all-reduces them between the phases (RCCL SUM):
+ *   FWD_GRAPHSUM : kvg  <- per-graph sums of the local rows            -> all-reduce kvg slots 1 and 3 (entry keys)
+ *   FWD_NODESUM  : kvn  <- per-node column sums of the local entries, diagonal entries weighted by diag_w
+ *                                                                       -> all-reduce kvn
+ *   FWD_APPLY    : att  <- all ten terms from kvg / kvn
+ *   BWD_QUERY    : dh1 (query slots), dh2 (query slots), dkvg, dkvn from datt, kvg, kvn
+ *                                                                       -> all-reduce dkvg slots 1 and 3, dkvn
+ *   BWD_KEYVAL   : dv, ck, dh2 (key slots, skip path), dh1 (key slots 10, 11) from dkvg / dkvn
+ * Buffers and shapes as for hotk_attn22_forward / _backward; kvn / dkvn rows of padding nodes are not touched. */
+enum { HOTK_ATTN22_FWD_GRAPHSUM = 0, HOTK_ATTN22_FWD_NODESUM = 1, HOTK_ATTN22_FWD_APPLY = 2,
+       HOTK_ATTN22_BWD_QUERY = 3, HOTK_ATTN22_BWD_KEYVAL = 4 };
+int hotk_attn22_phase(const hotk_attn22_args* args, int phase, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

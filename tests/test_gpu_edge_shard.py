@@ -1,7 +1,9 @@
-"""GPU (-m gpu): edge-shard mode of ONE graph over two ranks.  Both ranks share cuda:0 and talk over
+"""GPU (-m gpu): edge-shard mode of ONE graph over two / four ranks.  All ranks share cuda:0 and talk over
 gloo (host-staged collectives in hot_amd.dist stand in for RCCL, which needs one GPU per rank); the arithmetic on
 every rank is the HIP path.  Each rank checks its local outputs, its local input gradients and the all-reduced
-parameter gradients against the same layer run on the whole graph in one process."""
+parameter gradients against the same layer run on the whole graph in one process.  Two sharded paths: the fused core
+in phases (hotk_attn22_phase, all-reduces of kvg / kvn and their gradients between the phases) and the general
+kernels (all-reduce of the materialised key-value sums in ops.KernelAttn)."""
 import os
 import socket
 import sys
@@ -46,7 +48,7 @@ def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, fused):
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
@@ -69,6 +71,7 @@ def _worker(rank, world, port, q):
         ref_gp = {k: p.grad.clone() for k, p in layer.named_parameters()}
         # this rank's shard
         layer2 = _layer()
+        layer2.use_fused = fused
         Gs, own = shard_graph(nf.to(DEV), ei.to(DEV), ef.to(DEV), world, rank)
         rows = torch.cat([torch.arange(n, device=DEV), n + own])         # global row of every local row
         xs = Gs.values.clone().requires_grad_(True)
@@ -98,12 +101,13 @@ def _free_port():
     return port
 
 
-def test_edge_shard_two_ranks_matches_whole_graph():
+@pytest.mark.parametrize('world,fused', [(2, True), (2, False), (4, True)])
+def test_edge_shard_matches_whole_graph(world, fused):
     import torch.multiprocessing as mp
-    world, port = 2, _free_port()
+    port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused)) for r in range(world)]
     for p in procs:
         p.start()
     results = dict(q.get(timeout=200) for _ in range(world))
@@ -116,3 +120,30 @@ def test_edge_shard_two_ranks_matches_whole_graph():
     for rank, r in results.items():
         assert r['y'] < 1e-5, (rank, r)
         assert r['gx_edges'] < 2e-5 and r['gx_nodes'] < 2e-5 and r['gp'] < 2e-5, (rank, r)
+
+
+def test_fused_phases_single_rank_equal_one_pass():
+    """hotk_attn22_phase with a one-rank shard context (no exchange, diagonal weight 1) against hotk_attn22_forward /
+    _backward on the same batch: the phases share the arithmetic of the VALU/DPP kernels, the one-pass forward runs
+    the MFMA tiles, so outputs agree to rounding (1e-5) and not bitwise."""
+    from hot_amd import _lib
+    from hot_amd.batch import sparse as bs
+    from hot_amd.dist import ShardInfo
+    nf, ei, ef, g = _graph(seed=5, n=200)
+    n, E = nf.size(0), ei.size(1)
+    res = []
+    for sharded in (False, True):
+        layer = _layer()
+        G = bs.make_batch_concatenated(nf.to(DEV), ei.to(DEV), ef.to(DEV), [n], [E])
+        if sharded:
+            G.plan.shard = ShardInfo(0, 1, (G.plan.kind != 0).to(torch.float32))
+        x = G.values.clone().requires_grad_(True)
+        _lib.timing_begin(None)
+        y = layer(bs.batch_like(G, x, skip_masking=True))
+        y.values.square().sum().backward()
+        census = _lib.timing_end()
+        assert ('hotk_attn22_phase' in census) == sharded and ('hotk_attn22_forward' in census) != sharded, sorted(census)
+        res.append((y.values.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 2e-5
+    assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 2e-5
