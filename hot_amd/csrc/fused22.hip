@@ -505,6 +505,43 @@ __global__ void k_graph_reduce(const float* __restrict__ part, float* __restrict
   }
 }
 
+// The same for graphs with many chunks (one giant graph: B = 1, cpg = 4096): a block per (graph, slot, channel c), its
+// RG wave-sized groups each add every RG-th partial of the channel's 64 lanes, the groups' sums are added in group
+// order (deterministic), and the block writes the rotated copies that are taken from channel c.
+constexpr int RG = 16;
+__global__ __launch_bounds__(64 * RG) void k_graph_reduce_wide(const float* __restrict__ part, float* __restrict__ out,
+                                                               int64_t B, int cpg, int dup) {
+  __shared__ float sums[RG][64];
+  const int64_t X = (NC + 1) * 64;
+  const int lane = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  for (int64_t w = blockIdx.x; w < B * 4 * (NC + 1); w += gridDim.x) {
+    const int64_t bs = w / (NC + 1);
+    const int c = (int)(w - bs * (NC + 1));
+    const int64_t b = bs >> 2;
+    const int s = (int)(bs & 3);
+    float acc = 0.f;
+    for (int k = grp; k < cpg; k += RG) acc += part[((b * cpg + k) * 4 + s) * X + c * 64 + lane];
+    sums[grp][lane] = acc;
+    __syncthreads();
+    if (grp == 0) {
+      float t = sums[0][lane];
+#pragma unroll
+      for (int g = 1; g < RG; ++g) t += sums[g][lane];
+      sums[0][lane] = t;
+      out[bs * KVG_C * 64 + c * 64 + lane] = t;
+    }
+    __syncthreads();
+    // rotated copies out[b][s][9 + k][(h, x)] = sum[cidx(x)][(h, (x - k) & 15)]: the lanes whose cidx is this channel
+    {
+      const int k = grp, h = lane >> 4, xx = lane & 15;
+      const int cidx = dup ? (xx & 7) : (xx < NC ? xx : NC);
+      if (cidx == c) out[bs * KVG_C * 64 + (NC + 1 + k) * 64 + lane] = sums[0][h * 16 + ror_src(xx, k)];
+    }
+    __syncthreads();
+  }
+}
+static_assert(RG == NM, "k_graph_reduce_wide: one group per rotation");
+
 // ------------------------------------------------------------------------------------------------
 // node segments: one wave per (node, PART).  PART p owns the two column sums of slots 2p, 2p+1
 //   p = 0: terms 1, 2  (values v0 | v1^T, applied to the node's own query; also the node-level graph terms 7, 8)
@@ -1313,6 +1350,13 @@ void chunking(int64_t Emax, int* cpg, int* rows) {
   *rows = (int)((Emax + c - 1) / c);
 }
 
+void launch_graph_reduce(hipStream_t st, const float* part, float* out, int64_t B, int cpg, int dup) {
+  if (cpg > 16)
+    hipLaunchKernelGGL(k_graph_reduce_wide, dim3(hotk_grid(B * 4 * (NC + 1), 1, 256 * 16)), dim3(64 * RG), 0, st, part, out, B, cpg, dup);
+  else
+    hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(B * 4, 1, 256 * 16)), dim3(256), 0, st, part, out, B, cpg, dup);
+}
+
 }  // namespace
 
 extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes) {
@@ -1337,7 +1381,7 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   float* part = (float*)workspace;
   unsigned g1 = hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP);
   hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
-  hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4, 1, 256 * 16)), dim3(256), 0, st, part, a->kvg, a->B, cpg, 0);
+  launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   if (core_valu()) {
     hipLaunchKernelGGL((k_seg_fwd<1, true>), gseg, dim3(TPB), 0, st, *a);
@@ -1371,7 +1415,7 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
-  hipLaunchKernelGGL(k_graph_reduce, dim3(hotk_grid(a->B * 4, 1, 256 * 16)), dim3(256), 0, st, part, a->dkvg, a->B, cpg, 1);
+  launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
   hipLaunchKernelGGL(k_graphsum_bwd<true>, dim3(hotk_grid(a->B * ((a->Nmax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_graphsum_bwd<false>, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
@@ -1399,12 +1443,11 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   float* part = (float*)workspace;
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   const dim3 gchunk(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP));
-  const dim3 gred(hotk_grid(a->B * 4, 1, 256 * 16));
   switch (phase) {
     case HOTK_ATTN22_FWD_GRAPHSUM:
       if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
       hipLaunchKernelGGL(k_graphsum_fwd, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
-      hipLaunchKernelGGL(k_graph_reduce, gred, dim3(256), 0, st, part, a->kvg, a->B, cpg, 0);
+      launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
       break;
     case HOTK_ATTN22_FWD_NODESUM:
       hipLaunchKernelGGL(k_seg_kvsum<0>, gseg, dim3(TPB), 0, st, *a);
@@ -1431,7 +1474,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       if (phase == HOTK_ATTN22_BWD_QUERY) {
         if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
         hipLaunchKernelGGL(k_graph_apply_bwd, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
-        hipLaunchKernelGGL(k_graph_reduce, gred, dim3(256), 0, st, part, a->dkvg, a->B, cpg, 1);
+        launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
         hipLaunchKernelGGL((k_seg_bwd<1, 1>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<2, 1>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<0, 1>), gseg, dim3(TPB), 0, st, *a);

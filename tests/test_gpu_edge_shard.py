@@ -20,11 +20,11 @@ pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
 
-def _graph(seed=3, n=300):
+def _graph(seed=3, n=300, n_pairs=1200):
     rng = np.random.default_rng(seed)
     g = torch.Generator().manual_seed(seed)
     und = set()
-    while len(und) < 1200:
+    while len(und) < n_pairs:
         i, j = rng.integers(0, n, 2)
         if i != j:
             und.add((int(min(i, j)), int(max(i, j))))
@@ -147,3 +147,33 @@ def test_fused_phases_single_rank_equal_one_pass():
     (y0, gx0, gp0), (y1, gx1, gp1) = res
     assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 2e-5
     assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 2e-5
+
+
+@pytest.mark.parametrize('sharded', [False, True])
+def test_fused_one_large_graph_many_chunks(sharded):
+    """ONE graph with 3 000 nodes and ~21 000 entries: the per-graph sums are reduced from 83 row chunks
+    (k_graph_reduce_wide, taken above 16 chunks per graph) and column / row segments span the whole range of node ids.
+    Fused core (one pass, and in phases with a one-rank shard context) against the general kernels on the same batch.
+    ReLU features: a pre-activation within rounding of 0 may flip its gate between the two kernels, so gradients are
+    held row-wise as in test_gpu_parity.test_layer_vs_oracle_ba_graphs."""
+    from hot_amd.batch import sparse as bs
+    from hot_amd.dist import ShardInfo
+    nf, ei, ef, g = _graph(seed=9, n=3000, n_pairs=10000)
+    n, E = nf.size(0), ei.size(1)
+    res = []
+    for fused in (False, True):
+        layer = _layer()
+        layer.use_fused = fused
+        G = bs.make_batch_concatenated(nf.to(DEV), ei.to(DEV), ef.to(DEV), [n], [E])
+        assert G.plan.Emax > 16 * 256
+        if fused and sharded:
+            G.plan.shard = ShardInfo(0, 1, (G.plan.kind != 0).to(torch.float32))
+        x = G.values.clone().requires_grad_(True)
+        y = layer(bs.batch_like(G, x, skip_masking=True))
+        y.values.square().sum().backward()
+        res.append((y.values.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert _rel(y1, y0) < 1e-5
+    row_err = (gx1 - gx0).abs().amax(-1) / gx0.abs().max()
+    assert float((row_err > 2e-5).float().mean()) <= 2e-3
+    assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 1e-3
