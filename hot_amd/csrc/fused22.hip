@@ -798,7 +798,7 @@ __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict_
 #ifndef HOTK_GB_ROWS
 #define HOTK_GB_ROWS 64   /* rows per wave: the two d(KV) sums (50 registers) are loaded once per chunk; 16: 4.4 ms, 32: 3.8, 64: 3.6 */
 #endif
-constexpr int GB_ROWS = HOTK_GB_ROWS;
+constexpr int GB_ROWS = HOTK_GB_ROWS, GB_ROWS_SMALL = 16;   // SMALL: batches with too few 64-row chunks to fill the chip
 template <bool DIAG>
 __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, float* stage, int64_t b, int64_t ra,
                                                   int64_t rb) {
@@ -856,20 +856,20 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
 
 // wave per chunk of 16 consecutive rows of one kind of one graph; one instantiation per kind, so that only that kind's
 // two dKVg slots (F layout + rotated) are live
-template <bool DIAG>
+template <bool DIAG, int ROWS = GB_ROWS>
 __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t span = DIAG ? a.Nmax : a.Emax;
-  const int64_t cpg = (span + GB_ROWS - 1) / GB_ROWS;
+  const int64_t cpg = (span + ROWS - 1) / ROWS;
   const int64_t nwork = a.B * cpg;
   for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
     const int64_t b = w / cpg, k = w - b * cpg;
     const int64_t nn = a.n_nodes[b];
     const int64_t lo = b * a.Emax + (DIAG ? 0 : nn), hi = b * a.Emax + (DIAG ? nn : (int64_t)a.n_entries[b]);
-    const int64_t r0 = lo + k * GB_ROWS;
-    const int64_t r1 = r0 + GB_ROWS < hi ? r0 + GB_ROWS : hi;
+    const int64_t r0 = lo + k * ROWS;
+    const int64_t r1 = r0 + ROWS < hi ? r0 + ROWS : hi;
     graphsum_bwd_rows<DIAG>(L, a, stage, b, r0, r1);
   }
 }
@@ -1342,12 +1342,27 @@ bool core_valu() {
 #ifndef HOTK_CHUNK_ROWS
 #define HOTK_CHUNK_ROWS 256
 #endif
-void chunking(int64_t Emax, int* cpg, int* rows) {
-  int64_t c = (Emax + HOTK_CHUNK_ROWS - 1) / HOTK_CHUNK_ROWS;
+void chunking(int64_t B, int64_t Emax, int* cpg, int* rows) {
+  // small batches (C2: 128 molecules of <= 62 rows): shorter chunks, so that a few thousand waves share the rows
+  int64_t cr = HOTK_CHUNK_ROWS;
+  while (cr > 16 && B * ((Emax + cr - 1) / cr) < 2048) cr >>= 1;
+  int64_t c = (Emax + cr - 1) / cr;
   if (c > 4096) c = 4096;
   if (c < 1) c = 1;
   *cpg = (int)c;
   *rows = (int)((Emax + c - 1) / c);
+}
+
+void launch_graphsum_bwd(hipStream_t st, const A* a) {
+  if (a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS) < 2048) {
+    constexpr int RW = GB_ROWS_SMALL;
+    hipLaunchKernelGGL((k_graphsum_bwd<true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  } else {
+    constexpr int RW = GB_ROWS;
+    hipLaunchKernelGGL((k_graphsum_bwd<true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  }
 }
 
 void launch_graph_reduce(hipStream_t st, const float* part, float* out, int64_t B, int cpg, int dup) {
@@ -1362,7 +1377,7 @@ void launch_graph_reduce(hipStream_t st, const float* part, float* out, int64_t 
 extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes) {
   HOTK_CHECK_ARG(bytes && B >= 0 && Emax >= 0);
   int cpg, rows;
-  chunking(Emax, &cpg, &rows);
+  chunking(B, Emax, &cpg, &rows);
   *bytes = (size_t)B * cpg * 4 * (NC + 1) * 64 * sizeof(float);
   return HOTK_OK;
 }
@@ -1374,7 +1389,7 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
   int cpg, rows;
-  chunking(a->Emax, &cpg, &rows);
+  chunking(a->B, a->Emax, &cpg, &rows);
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
@@ -1409,15 +1424,14 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
   int cpg, rows;
-  chunking(a->Emax, &cpg, &rows);
+  chunking(a->B, a->Emax, &cpg, &rows);
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
   float* part = (float*)workspace;
   hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
   launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
-  hipLaunchKernelGGL(k_graphsum_bwd<true>, dim3(hotk_grid(a->B * ((a->Nmax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL(k_graphsum_bwd<false>, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+  launch_graphsum_bwd(st, a);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(TPB), 0, st, *a);
   hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(TPB), 0, st, *a);
@@ -1437,7 +1451,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
   int cpg, rows;
-  chunking(a->Emax, &cpg, &rows);
+  chunking(a->B, a->Emax, &cpg, &rows);
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   float* part = (float*)workspace;
@@ -1479,8 +1493,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
         hipLaunchKernelGGL((k_seg_bwd<2, 1>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<0, 1>), gseg, dim3(TPB), 0, st, *a);
       } else {
-        hipLaunchKernelGGL(k_graphsum_bwd<true>, dim3(hotk_grid(a->B * ((a->Nmax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL(k_graphsum_bwd<false>, dim3(hotk_grid(a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+        launch_graphsum_bwd(st, a);
         hipLaunchKernelGGL((k_seg_bwd<1, 2>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<2, 2>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<0, 2>), gseg, dim3(TPB), 0, st, *a);

@@ -148,11 +148,23 @@ __global__ __launch_bounds__(256) void k_bias_grad_rows4(const float* __restrict
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
   if (ty < TY) {
-    for (int64_t r = r0 + ty; r < r1; r += TY) {
-      const uint8_t kd = kind[r];
-      if (kd == 0) continue;
-      const float4 v = *reinterpret_cast<const float4*>(dy + r * ld + 4 * cv);
-      if (kd == 2) a_off = vadd(a_off, v); else a_diag = vadd(a_diag, v);
+    // four rows per step so that four loads are in flight (a short strip is latency bound otherwise)
+    for (int64_t r = r0 + ty; r < r1; r += 4 * TY) {
+      uint8_t kd[4];
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int64_t rr = r + (int64_t)u * TY;
+        kd[u] = rr < r1 ? kind[rr] : (uint8_t)0;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (kd[u]) v[u] = *reinterpret_cast<const float4*>(dy + (r + (int64_t)u * TY) * ld + 4 * cv);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (kd[u] == 2) a_off = vadd(a_off, v[u]);
+        else if (kd[u] == 1) a_diag = vadd(a_diag, v[u]);
+      }
     }
   }
   red[0][threadIdx.x] = a_off;
@@ -408,7 +420,7 @@ extern "C" int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* k
   hipStream_t st = (hipStream_t)stream;
   if (C % 4 == 0 && C / 4 <= 256 && ld % 4 == 0 && hotk_aligned16(dy)) {
     const int C4 = (int)(C / 4), TY = 256 / C4;
-    int64_t nb = hotk_grid(n, 512, 4096);
+    int64_t nb = hotk_grid(n, 16 * TY, 4096);   // >= 16 rows per thread unless that needs more than 4096 blocks
     int64_t rpb = (n + nb - 1) / nb;
     nb = (n + rpb - 1) / rpb;
     hipLaunchKernelGGL(k_bias_grad_rows4, dim3((unsigned)nb), dim3(256), 0, st, dy, ld, kind, db_off, db_diag, n, C4, TY,
