@@ -67,7 +67,7 @@ class Attn22Args(ctypes.Structure):
                  ('datt', _P), ('ld_datt', _L), ('dout', _P), ('ld_dout', _L),
                  ('dh1', _P), ('ld_dh1', _L), ('dh2', _P), ('ld_dh2', _L), ('dv', _P), ('ld_dv', _L),
                  ('ck', _P), ('dkvg', _P),
-                 ('kvn', _P), ('dkvn', _P), ('diag_w', ctypes.c_float)])
+                 ('kvn', _P), ('dkvn', _P), ('nd0', _P), ('dd0', _P), ('diag_w', ctypes.c_float)])
 
 
 # phases of hotk_attn22_phase (include/hotk.h)

@@ -614,20 +614,84 @@ __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float*
 // split-phase mode: the two sums of (node n, part P) in memory, [9][64] floats each, feature-major like part_store
 constexpr int64_t KVN_SLOT = (NC + 1) * 64;
 template <int P>
-__device__ __forceinline__ float* kvn_slot(float* base, int64_t n, int s) { return base + ((n * 3 + P) * 2 + s) * KVN_SLOT; }
+__device__ __forceinline__ float* kvn_slot(const A& a, int64_t n, int s) { return a.kvn + ((P * a.Nn + n) * 2 + s) * KVN_SLOT; }
+template <int P>   // d(sums) of parts 1 and 2 only: part 0 exchanges [d num | d den] of the node queries instead (dd0)
+__device__ __forceinline__ float* dkvn_slot(const A& a, int64_t n, int s) {
+  static_assert(P >= 1, "part 0 has no dkvn");
+  return a.dkvn + (((P - 1) * a.Nn + n) * 2 + s) * KVN_SLOT;
+}
 
-// phase FWD_NODESUM: the weighted local column sums of every valid node, for the caller to all-reduce
+// phase FWD_NODESUM: the weighted local column sums of every valid node.  Parts 1 and 2 are applied to ENTRIES, which
+// live on any rank: their sums are all-reduced.  Part 0 is applied to the node's own query, which every rank holds:
+// phi(q) . KV is linear in KV, so a rank applies its PARTIAL sums and only [numerator | normaliser] (nd0: 64 floats per
+// slot in the C layout instead of 576) is all-reduced; the partial sums stay local for the backward pass.
 template <int P>
 __global__ __launch_bounds__(TPB) void k_seg_kvsum(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
+  __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
+  float* kvbuf = kvbuf_all[threadIdx.x >> 6];
   for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float kv[2][NC + 1];
     seg_accumulate<P, true>(L, a, stage, (int32_t)n, kv);
-    part_store(L, kvn_slot<P>(a.kvn, n, 0), kv[0]);
-    part_store(L, kvn_slot<P>(a.kvn, n, 1), kv[1]);
+    part_store(L, kvn_slot<P>(a, n, 0), kv[0]);
+    part_store(L, kvn_slot<P>(a, n, 1), kv[1]);
+    if (P == 0) {
+      float rot0[NM], rot1[NM];
+      kv_to_rot<false>(L, kvbuf, kv[0], rot0);
+      kv_to_rot<false>(L, kvbuf, kv[1], rot1);
+      const float* q = a.h1 + n * a.ld_h1;
+      const float r[1] = {q[L.lane]};
+      stage_put<1>(L, stage, r);
+      float x[8];
+      slice8(L, stage + 0 * SLOT, x);
+      a.nd0[(n * 2 + 0) * 64 + L.lane] = rot_dot(phi_of(pre_x(L, x)), rot0);
+      slice8(L, stage + 1 * SLOT, x);
+      a.nd0[(n * 2 + 1) * 64 + L.lane] = rot_dot(phi_of(pre_x(L, x)), rot1);
+    }
+  }
+}
+
+// phase FWD_APPLY, part 0: terms 1, 2 of node n from the all-reduced [numerator | normaliser] (same quotient as apply_fwd)
+__global__ __launch_bounds__(TPB) void k_node_apply_nd(A a) {
+  const int lane = threadIdx.x & 63, h = lane >> 4, x = lane & 15;
+  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+    if (!a.nkind[n]) continue;
+    float* o = a.att + rowoff(a.diag_pos[n], a.ld_att);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float num = a.nd0[(n * 2 + s) * 64 + lane];
+      const float den = fmaxf(ror<8>(num), 1e-30f);
+      const float v = num * __builtin_amdgcn_rcpf(den);
+      if (x < NC) o[s * SLOT + h * NC + x] = v;
+    }
+  }
+}
+
+// phase BWD_QUERY, part 0: [d num | d den] of the node queries of THIS rank's (weighted) output gradient, from the
+// all-reduced nd0 -- the quotient rule of apply_bwd; the caller all-reduces dd0 (the rule is linear in the gradient)
+__global__ __launch_bounds__(TPB) void k_node_dd(A a) {
+  const int lane = threadIdx.x & 63, h = lane >> 4, x = lane & 15;
+  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+    if (!a.nkind[n]) continue;
+    const float* g = a.datt + rowoff(a.diag_pos[n], a.ld_datt);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      const float num = a.nd0[(n * 2 + s) * 64 + lane];
+      float den = ror<8>(num);                                  // lanes x < 8: the normaliser of their head
+      const float gc = x < NC ? g[s * SLOT + h * NC + x] : 0.f;
+      const float dot = head_allsum(x < NC ? gc * num : 0.f);
+      const bool guarded = (den == 0.f);
+      if (guarded) den = 1e-5f;
+      const float inv = __builtin_amdgcn_rcpf(den);
+      const float dden = guarded ? 0.f : -dot * inv * inv;
+      // lanes x >= 8 read the normaliser of lane x - 8 through ror<8>, i.e. a numerator: their dden is recomputed
+      // from lane 0's value below
+      const float dden0 = __shfl(dden, h * 16, 64);
+      a.dd0[(n * 2 + s) * 64 + lane] = x < NC ? gc * inv : dden0;
+    }
   }
 }
 
@@ -646,8 +710,8 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
     {
       float kv[2][NC + 1];
       if (LOADKV) {
-        kvg_load(L, kvn_slot<P>(a.kvn, n, 0), kv[0]);
-        kvg_load(L, kvn_slot<P>(a.kvn, n, 1), kv[1]);
+        kvg_load(L, kvn_slot<P>(a, n, 0), kv[0]);
+        kvg_load(L, kvn_slot<P>(a, n, 1), kv[1]);
       } else {
         seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
       }
@@ -881,7 +945,8 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
 #define HOTK_SEGB_WAVES 4
 #endif
 // MODE 0: the whole backward of a (node, part).  Split-phase mode: MODE 1 = query side only (the node's sums come from
-// a.kvn, d(sums) go to a.dkvn for the caller to all-reduce), MODE 2 = key / value side only (d(sums) from a.dkvn)
+// a.kvn, d(sums) go to a.dkvn for the caller to all-reduce), MODE 2 = key / value side only (d(sums) from a.dkvn),
+// MODE 3 = key / value side of part 0 (d(sums) rebuilt from the all-reduced [d num | d den] of the node queries)
 template <int P, int MODE = 0>
 __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
@@ -893,15 +958,45 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
   for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float dkv[2][NC + 1];
-    if (MODE == 2) {
-      kvg_load(L, kvn_slot<P>(a.dkvn, n, 0), dkv[0]);
-      kvg_load(L, kvn_slot<P>(a.dkvn, n, 1), dkv[1]);
+    if constexpr (MODE == 3) {
+      // part 0, key / value side in split-phase mode: d(sums) = phi(q) (x) [d num | d den] from the all-reduced dd0; the
+      // query gradient takes this rank's PARTIAL sums (the caller adds node gradients over ranks)
+      static_assert(P == 0 || MODE != 3, "MODE 3 is part 0 only");
+      float kv[2][NC + 1];
+      kvg_load(L, kvn_slot<P>(a, n, 0), kv[0]);
+      kvg_load(L, kvn_slot<P>(a, n, 1), kv[1]);
+      const float r[3] = {a.h1[n * a.ld_h1 + L.lane], a.dd0[(n * 2 + 0) * 64 + L.lane], a.dd0[(n * 2 + 1) * 64 + L.lane]};
+      stage_put<3>(L, stage, r);
+      float* dq = a.dh1 + n * a.ld_dh1;
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        float x[8];
+        slice8(L, stage + s * SLOT, x);
+        const float* dp = stage + 64 * (1 + s) + L.h * 16;     // [d num 0..7 | d den] of head h
+        const float4 d0 = *reinterpret_cast<const float4*>(dp), d1 = *reinterpret_cast<const float4*>(dp + 4);
+        const float dn[NC] = {d0.x, d0.y, d0.z, d0.w, d1.x, d1.y, d1.z, d1.w};
+        const float dd = dp[NC];
+        const float pre = pre_x(L, x);
+        const float phi = phi_of(pre);
+        float dphi = kv[s][NC] * dd;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          dphi = fmaf(kv[s][c], dn[c], dphi);
+          dkv[s][c] = phi * dn[c];
+        }
+        dkv[s][NC] = phi * dd;
+        const float d = rot_dot(pre > 0.f ? dphi : 0.f, L.pr);
+        if (L.x < DH) dq[s * SLOT + L.h * DH + L.x] = d;
+      }
+    } else if constexpr (MODE == 2) {
+      kvg_load(L, dkvn_slot<P>(a, n, 0), dkv[0]);
+      kvg_load(L, dkvn_slot<P>(a, n, 1), dkv[1]);
     } else {
       kv_zero<2>(dkv);
       float kv[2][NC + 1];
       if (MODE == 1) {
-        kvg_load(L, kvn_slot<P>(a.kvn, n, 0), kv[0]);
-        kvg_load(L, kvn_slot<P>(a.kvn, n, 1), kv[1]);
+        kvg_load(L, kvn_slot<P>(a, n, 0), kv[0]);
+        kvg_load(L, kvn_slot<P>(a, n, 1), kv[1]);
       } else {
         seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
       }
@@ -957,9 +1052,9 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
         }
       }
     }
-    if (MODE == 1) {
-      part_store(L, kvn_slot<P>(a.dkvn, n, 0), dkv[0]);
-      part_store(L, kvn_slot<P>(a.dkvn, n, 1), dkv[1]);
+    if constexpr (MODE == 1) {
+      part_store(L, dkvn_slot<P>(a, n, 0), dkv[0]);
+      part_store(L, dkvn_slot<P>(a, n, 1), dkv[1]);
       continue;
     }
     // key / value side of this part's two column sums: dV of the plain slot goes to row e, dV of the transposed
@@ -967,7 +1062,7 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
     float drot0[NM], drot1[NM];
     kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
     kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
-    for_col_entries<P, MODE == 2>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
+    for_col_entries<P, (MODE >= 2)>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
       float* dve = a.dv + rowoff(e, a.ld_dv);
       float* dvt = te >= 0 ? a.dv + rowoff(te, a.ld_dv) : nullptr;
       float* ck = a.ck + rowoff(e, 6 * SLOT) + 2 * P * SLOT;
@@ -980,14 +1075,14 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      if (MODE == 2) kv_bwd_phi_w(L, phi0, w, val, dkv[0], drot0, d0, ck);
+      if (MODE >= 2) kv_bwd_phi_w(L, phi0, w, val, dkv[0], drot0, d0, ck);
       else kv_bwd_phi(L, phi0, val, dkv[0], drot0, d0, ck);
       slice8(L, stage + 1 * SLOT, val);
       if (P != 2 && te < 0) {
 #pragma unroll
         for (int c = 0; c < NC; ++c) val[c] = 0.f;
       }
-      if (MODE == 2) kv_bwd_phi_w(L, phi1, w, val, dkv[1], drot1, d1, ck + SLOT);
+      if (MODE >= 2) kv_bwd_phi_w(L, phi1, w, val, dkv[1], drot1, d1, ck + SLOT);
       else kv_bwd_phi(L, phi1, val, dkv[1], drot1, d1, ck + SLOT);
       if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
     });
@@ -1447,7 +1542,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   int rc = check_args(a);
   if (rc) return rc;
   HOTK_CHECK_ARG(phase >= HOTK_ATTN22_FWD_GRAPHSUM && phase <= HOTK_ATTN22_BWD_KEYVAL);
-  HOTK_CHECK_ARG(a->kvg && a->kvn && hotk_aligned16(a->kvn) && a->diag_w > 0.f);
+  HOTK_CHECK_ARG(a->kvg && a->kvn && a->nd0 && hotk_aligned16(a->kvn) && a->diag_w > 0.f);
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
   int cpg, rows;
@@ -1475,12 +1570,12 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       hipLaunchKernelGGL(k_graph_apply_fwd_t, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
       hipLaunchKernelGGL((k_seg_fwd<1, false, true>), gseg, dim3(TPB), 0, st, *a);
       hipLaunchKernelGGL((k_seg_fwd<2, false, true>), gseg, dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL((k_seg_fwd<0, false, true>), gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL(k_node_apply_nd, gseg, dim3(TPB), 0, st, *a);
       break;
     }
     case HOTK_ATTN22_BWD_QUERY:
     case HOTK_ATTN22_BWD_KEYVAL:
-      HOTK_CHECK_ARG(a->dkvn && hotk_aligned16(a->dkvn) && a->datt && a->dh1 && a->dh2 && a->dv && a->ck && a->dkvg);
+      HOTK_CHECK_ARG(a->dkvn && a->dd0 && hotk_aligned16(a->dkvn) && a->datt && a->dh1 && a->dh2 && a->dv && a->ck && a->dkvg);
       HOTK_CHECK_ARG(a->ld_datt >= 10 * SLOT && a->ld_dh1 >= 12 * SLOT && a->ld_dh2 >= 8 * SLOT + a->D && a->D >= 0 &&
                      a->ld_dv >= 10 * SLOT);
       HOTK_CHECK_ARG(((a->ld_datt | a->ld_dh1 | a->ld_dh2 | a->ld_dv) & 3) == 0 && hotk_aligned16(a->datt));
@@ -1491,12 +1586,12 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
         launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
         hipLaunchKernelGGL((k_seg_bwd<1, 1>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<2, 1>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<0, 1>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL(k_node_dd, gseg, dim3(TPB), 0, st, *a);
       } else {
         launch_graphsum_bwd(st, a);
         hipLaunchKernelGGL((k_seg_bwd<1, 2>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL((k_seg_bwd<2, 2>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<0, 2>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<0, 3>), gseg, dim3(TPB), 0, st, *a);
       }
       break;
   }

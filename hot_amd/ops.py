@@ -679,12 +679,14 @@ class AttnCore22(Function):
         else:
             # edge-shard mode (hot_amd.dist): the sums over ENTRIES are partial on a rank; the core runs in phases and
             # the sums are all-reduced in between (per-graph sums of entry keys = kvg slots 1, 3; all per-node sums)
-            kvn = (torch.empty if plan.B == 1 else torch.zeros)(plan.Nn, 3 * 2 * 9 * 64, dtype=torch.float32, device=dev)
-            a.kvn, a.diag_w = kvn.data_ptr(), 1.0 / shard.world
+            # kvn = [part 0 sums (rank-local) | part 1, 2 sums | nd0]: everything after part 0 is ONE all-reduce
+            P1 = plan.Nn * 1152
+            kvn = (torch.empty if plan.B == 1 else torch.zeros)(3 * P1 + plan.Nn * 128, dtype=torch.float32, device=dev)
+            a.kvn, a.nd0, a.diag_w = kvn.data_ptr(), kvn.data_ptr() + 4 * 3 * P1, 1.0 / shard.world
             AttnCore22._phase(a, _lib.ATTN22_FWD_GRAPHSUM, ws, nws, 4 * plan.Ev * 4 * 32)
             AttnCore22._reduce_entry_slots(shard, kvg)
             AttnCore22._phase(a, _lib.ATTN22_FWD_NODESUM, ws, nws, 4 * plan.Ev * 6 * 32 + 4 * kvn.numel())
-            shard.all_reduce_(kvn)
+            shard.all_reduce_(kvn[P1:])
             AttnCore22._phase(a, _lib.ATTN22_FWD_APPLY, ws, nws, 4 * plan.Ev * (6 * 32 + 10 * 32) + 4 * kvn.numel())
         skip = h2.view(plan.R, -1)[:, 256:]
         if not padded and thin_ok(plan.R, 320, D):
@@ -748,8 +750,11 @@ class AttnCore22(Function):
                  byref(a), p(ws), nws)
         else:
             # backward of the forward all-reduces: every rank needs the full d(sums) before its key / value side
-            dkvn = (torch.empty_like if plan.B == 1 else torch.zeros_like)(kvn)
-            a.kvn, a.dkvn, a.diag_w = kvn.data_ptr(), dkvn.data_ptr(), 1.0 / shard.world
+            # dkvn = [d(part 1, 2 sums) | dd0]: one all-reduce
+            P1 = plan.Nn * 1152
+            dkvn = (torch.empty if plan.B == 1 else torch.zeros)(2 * P1 + plan.Nn * 128, dtype=torch.float32, device=dev)
+            a.kvn, a.nd0, a.diag_w = kvn.data_ptr(), kvn.data_ptr() + 4 * 3 * P1, 1.0 / shard.world
+            a.dkvn, a.dd0 = dkvn.data_ptr(), dkvn.data_ptr() + 4 * 2 * P1
             AttnCore22._phase(a, _lib.ATTN22_BWD_QUERY, ws, nws, 4 * plan.Ev * (6 * 32 * 2 + 10 * 32) + 8 * kvn.numel())
             AttnCore22._reduce_entry_slots(shard, dkvg)
             shard.all_reduce_(dkvn)

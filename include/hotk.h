@@ -263,8 +263,11 @@ typedef struct hotk_attn22_args {
   float* ck;
   float* dkvg;
   /* split-phase (edge-shard) mode only, see hotk_attn22_phase; ignored by hotk_attn22_forward / _backward */
-  float* kvn;   /* [Nn][3 parts][2 slots][9][64] per-node key-value sums (feature-major, as the 9 first kvg channels) */
-  float* dkvn;  /* same shape: their gradients */
+  float* kvn;   /* [3 parts][Nn][2 slots][9][64] per-node key-value sums (feature-major, as the 9 first kvg channels);
+                   part 0 (applied to the node's own query) stays rank-local, parts 1 and 2 are all-reduced */
+  float* dkvn;  /* [2][Nn][2][9][64]: gradients of the sums of parts 1 and 2 */
+  float* nd0;   /* [Nn][2 slots][64] part 0: phi(q) . sums = [8 numerators | normaliser] per head (16 lanes), all-reduced */
+  float* dd0;   /* [Nn][2][64] part 0: [d numerators | d normaliser] of the node queries, all-reduced */
   float diag_w; /* weight of a diagonal entry in the per-node sums (1/world: every rank holds all diagonal entries) */
 } hotk_attn22_args;
 int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes);
@@ -275,12 +278,15 @@ int hotk_attn22_backward(const hotk_attn22_args* args, void* workspace, size_t w
  * no multi-device form of kernelattncoef.py:103-175, the sums are what its coalesce() builds on one device).  Sums over
  * ENTRIES are partial on a rank: the caller all-reduces them between the phases (RCCL SUM):
  *   FWD_GRAPHSUM : kvg  <- per-graph sums of the local rows            -> all-reduce kvg slots 1 and 3 (entry keys)
- *   FWD_NODESUM  : kvn  <- per-node column sums of the local entries, diagonal entries weighted by diag_w
- *                                                                       -> all-reduce kvn
- *   FWD_APPLY    : att  <- all ten terms from kvg / kvn
- *   BWD_QUERY    : dh1 (query slots), dh2 (query slots), dkvg, dkvn from datt, kvg, kvn
- *                                                                       -> all-reduce dkvg slots 1 and 3, dkvn
- *   BWD_KEYVAL   : dv, ck, dh2 (key slots, skip path), dh1 (key slots 10, 11) from dkvg / dkvn
+ *   FWD_NODESUM  : kvn  <- per-node column sums of the local entries, diagonal entries weighted by diag_w;
+ *                  nd0  <- part 0's partial sums applied to the node queries (linear in the sums, and every rank
+ *                          holds every node query: 128 floats per node cross the ranks instead of 1 152)
+ *                                                                       -> all-reduce kvn parts 1, 2 and nd0
+ *   FWD_APPLY    : att  <- all ten terms from kvg / kvn / nd0
+ *   BWD_QUERY    : dh1 (query slots 2, 3), dh2 (query slots), dkvg, dkvn, dd0 from datt, kvg, kvn, nd0
+ *                                                                       -> all-reduce dkvg slots 1 and 3, dkvn, dd0
+ *   BWD_KEYVAL   : dv, ck, dh2 (key slots, skip path), dh1 (query slots 0, 1 from this rank's partial part-0 sums;
+ *                  key slots 10, 11) from dkvg / dkvn / dd0
  * Buffers and shapes as for hotk_attn22_forward / _backward; kvn / dkvn rows of padding nodes are not touched. */
 enum { HOTK_ATTN22_FWD_GRAPHSUM = 0, HOTK_ATTN22_FWD_NODESUM = 1, HOTK_ATTN22_FWD_APPLY = 2,
        HOTK_ATTN22_BWD_QUERY = 3, HOTK_ATTN22_BWD_KEYVAL = 4 };
