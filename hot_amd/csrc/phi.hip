@@ -110,6 +110,58 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_bwd(const float* __res
   }
 }
 
+// d == 8, m == 16: the backward twin of k_phi_relu_fwd_8x16.  Thread (head, feature mm) recomputes ITS pre-activation
+// (the forward's fmaf chain: identical gate), the 16 gated gradients of a head meet in LDS, and the head's threads
+// mm < 8 contract them with column k = mm of the projection (held in registers), in feature order like the generic
+// kernel.  8 + 16 multiply-adds per thread instead of 16 x 8 + 16 per output element and no 64-bit division.
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_bwd_8x16(const float* __restrict__ x, int64_t ld_x,
+                                                                   const float* __restrict__ proj,
+                                                                   const uint8_t* __restrict__ kind, unsigned keep,
+                                                                   const float* __restrict__ dphi, int64_t ld_dphi,
+                                                                   float* __restrict__ dx, int64_t ld_dx, int64_t n, int HH,
+                                                                   float scale) {
+  __shared__ float gs[PHI_THREADS];
+  const int mm = threadIdx.x & 15, k = mm & 7;
+  float pr[8], pk[16];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) pr[j] = proj[mm * 8 + j];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) pk[j] = proj[j * 8 + k];
+  const int F = HH * 16;
+  const float* g16 = gs + (threadIdx.x & ~15);
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const bool on = !kind || hotk_keep(keep, kind[r]);
+    const float* xr = x + r * ld_x;
+    for (int f0 = 0; f0 < F; f0 += PHI_THREADS) {   // block-uniform trip count: the barriers below are reached by all
+      const int f = f0 + threadIdx.x, hh = f >> 4;
+      const bool act = f < F;
+      float gm = 0.f;
+      if (on && act) {
+        const float4 a = *reinterpret_cast<const float4*>(xr + hh * 8);
+        const float4 b = *reinterpret_cast<const float4*>(xr + hh * 8 + 4);
+        float s = 0.f;
+        s = fmaf(a.x * scale, pr[0], s); s = fmaf(a.y * scale, pr[1], s);
+        s = fmaf(a.z * scale, pr[2], s); s = fmaf(a.w * scale, pr[3], s);
+        s = fmaf(b.x * scale, pr[4], s); s = fmaf(b.y * scale, pr[5], s);
+        s = fmaf(b.z * scale, pr[6], s); s = fmaf(b.w * scale, pr[7], s);
+        if (s > 0.f) gm = dphi[r * ld_dphi + f];
+      }
+      gs[threadIdx.x] = gm;
+      __syncthreads();
+      if (act && mm < 8) {
+        float acc = 0.f;
+        if (on) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc = fmaf(g16[j], pk[j], acc);
+          acc *= scale;
+        }
+        dx[r * ld_dx + hh * 8 + k] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // ------------------------------------------------------------------ softmax maps
 // mode 1 (query): stabiliser = max over the head's m features; mode 2 (key): stabiliser = gstat[0]
 __global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_fwd(const float* __restrict__ x, int64_t ld_x,
@@ -350,7 +402,10 @@ extern "C" int hotk_phi_bwd(const float* x, int64_t ld_x, const float* proj, con
   HOTK_CHECK_ARG(mode != HOTK_PHI_SOFTMAX_K || gstat);
   hipStream_t st = (hipStream_t)stream;
   const float scale = powf((float)d, -0.25f);
-  if (mode == HOTK_PHI_RELU) {
+  if (mode == HOTK_PHI_RELU && d == 8 && m == 16 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0) {
+    hipLaunchKernelGGL(k_phi_relu_bwd_8x16, dim3(hotk_grid(n, 1, 256 * 32)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
+                       kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, scale);
+  } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_bwd, dim3(hotk_grid(n * HH * d, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, d, m, scale);
   } else {
