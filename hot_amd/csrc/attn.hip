@@ -9,7 +9,7 @@
 namespace {
 
 constexpr int AT_THREADS = 256;
-constexpr int AT_CT = 8;  // value channels accumulated per thread and pass
+constexpr int AT_CT = 9;  // channels accumulated per thread and pass: c = 8 values + the normaliser in ONE walk of the segment
 
 // work item = (segment, chunk, channel tile, feature); consecutive lanes -> consecutive features, so the
 // key row is read as contiguous 256-B pieces and the value channels are wave-broadcast loads.
@@ -142,6 +142,54 @@ __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats(
   }
 }
 
+// The same with a thread per (row, head, channel) for c in {1, 2, 4, 8, 16, 32, 64}: the c threads of a head are c
+// consecutive lanes (groups aligned in the wave), each contracts ITS channel and the normaliser with the query -- 8
+// lanes read 8 consecutive floats of a key-value row instead of one lane walking all 144 -- and the dot product
+// dO . O meets through xor shuffles.  Same fmaf chains per channel as above; the channel sum is a tree instead of a loop.
+template <int C>
+__global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
+    const float* __restrict__ Q, int64_t ld_q, const float* __restrict__ KV, const int32_t* __restrict__ sidx,
+    int64_t seg_div, const uint8_t* __restrict__ kind, unsigned keep, const float* __restrict__ dO, int64_t ld_do,
+    float* __restrict__ X, int64_t ld_x, float* __restrict__ XA, int64_t ld_xa, int64_t n, int HH, int m) {
+  constexpr int c1 = C + 1;
+  const int F = HH * m, W = HH * C;
+  const int64_t total = n * W;
+  // every lane of a wave runs the same number of iterations (total is padded), so the shuffles see whole groups
+  const int64_t padded = (total + 63) & ~(int64_t)63;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += (int64_t)gridDim.x * blockDim.x) {
+    const bool live = t < total;
+    const int64_t r = live ? t / W : 0;
+    const int w = (int)(t - r * W);
+    const int hh = live ? w / C : 0, chn = w - hh * C;
+    const int64_t s = live ? seg_of(sidx, seg_div, r) : -1;
+    const bool on = live && s >= 0 && (!kind || hotk_keep(keep, kind[r]));
+    float x = 0.f, part = 0.f, inv = 0.f;
+    bool guarded = false;
+    if (on) {
+      const float* q = Q + r * ld_q + hh * m;
+      const float* kv = KV + ((int64_t)s * F + hh * m) * c1;
+      float num = 0.f, den = 0.f;
+      for (int mm = 0; mm < m; ++mm) {
+        const float qv = q[mm];
+        num = fmaf(qv, kv[mm * c1 + chn], num);
+        den = fmaf(qv, kv[mm * c1 + C], den);
+      }
+      guarded = (den == 0.f);
+      if (guarded) den = 1e-5f;
+      inv = 1.f / den;
+      const float gv = dO[r * ld_do + w];
+      x = gv * inv;
+      part = gv * (num * inv);
+    }
+#pragma unroll
+    for (int o = 1; o < C; o <<= 1) part += __shfl_xor(part, o, 64);
+    if (live) {
+      X[r * ld_x + w] = x;
+      if (chn == 0) XA[r * ld_xa + hh] = (on && !guarded) ? -part * inv : 0.f;
+    }
+  }
+}
+
 // thread per (row, feature)
 __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
     const float* __restrict__ KV, const int32_t* __restrict__ sidx, int64_t seg_div, const float* __restrict__ X,
@@ -213,9 +261,20 @@ extern "C" int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* K
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(Q && KV && dO && X && XA && ld_q >= (int64_t)HH * m && ld_do >= (int64_t)HH * c &&
                  ld_x >= (int64_t)HH * c && ld_xa >= HH);
-  hipLaunchKernelGGL(k_apply_bwd_stats, dim3(hotk_grid(n * HH, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
-                     (hipStream_t)stream, Q, ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH,
-                     m, c);
+  hipStream_t st = (hipStream_t)stream;
+#define HOTK_ABS_CASE(CC)                                                                                              \
+  case CC:                                                                                                             \
+    hipLaunchKernelGGL(k_apply_bwd_stats_c<CC>, dim3(hotk_grid(n * HH * CC, AT_THREADS, 256 * 32)), dim3(AT_THREADS),  \
+                       0, st, Q, ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH, m);        \
+    break;
+  switch (c) {
+    HOTK_ABS_CASE(1) HOTK_ABS_CASE(2) HOTK_ABS_CASE(4) HOTK_ABS_CASE(8) HOTK_ABS_CASE(16) HOTK_ABS_CASE(32)
+    HOTK_ABS_CASE(64)
+    default:
+      hipLaunchKernelGGL(k_apply_bwd_stats, dim3(hotk_grid(n * HH, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0, st, Q,
+                         ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH, m, c);
+  }
+#undef HOTK_ABS_CASE
   return hotk_launch_status();
 }
 
