@@ -19,10 +19,36 @@
 // addends of the next 32-column tile are requested before the current tile is finished (and before the next MFMA
 // loop), so their latency overlaps the matrix work.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// ---- fp32 products on the bf16 matrix pipe (B6 kernels) -------------------------------------------------------------
+// An fp32 number is EXACTLY the sum of three bf16 numbers: hi = its top 8 significant bits (mantissa truncated), mid =
+// the top 8 bits of the exact remainder, lo = what is left (<= 8 bits).  x . w then is nine bf16 products; the six of
+// relative weight >= 2^-16 (hi.hi, hi.mid, mid.hi, hi.lo, lo.hi, mid.mid) are summed in the fp32 accumulator of
+// v_mfma_f32_32x32x16_bf16 and the other three (<= 2^-24 of the product each) dropped: 1.9e-7 relative against fp64 on
+// [1 M, 64] x [64, 288] (scratch/bf16_split_probe.py; the fp32 library GEMM: 4.8e-7), at 6 x 32 cycles per 16 k instead
+// of 8 x 64 for v_mfma_f32_32x32x2_f32.
+__device__ __forceinline__ uint32_t f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+// planes of two consecutive k values packed as bf16 pairs (low half = first k)
+__device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t h0 = f2u(x0) & 0xffff0000u, h1 = f2u(x1) & 0xffff0000u;
+  const float r0 = x0 - u2f(h0), r1 = x1 - u2f(h1);
+  const uint32_t m0 = f2u(r0) & 0xffff0000u, m1 = f2u(r1) & 0xffff0000u;
+  const float s0 = r0 - u2f(m0), s1 = r1 - u2f(m1);
+  hi = (h0 >> 16) | h1;
+  mid = (m0 >> 16) | m1;
+  lo = (f2u(s0) >> 16) | (f2u(s1) & 0xffff0000u);
+}
+__device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
 #ifndef HOTK_ENTRY_WAVES
 #define HOTK_ENTRY_WAVES 8   /* measured at 10 M rows: 4 waves 7.9 ms, 8 waves 6.1 ms, 16 waves (128 VGPRs, spills) 6.7 ms */
 #endif
@@ -79,17 +105,36 @@ __device__ __forceinline__ void gemm_wave_fence() {
   __builtin_amdgcn_wave_barrier();
 }
 
-template <int KH, int TG, int MODE, int NW>
+// B6: the products run as six bf16 MFMAs per 16 k (see above).  The weight sits in LDS as three bf16 planes
+// [plane][k / 16][col][16 k] (a lane's A fragment = one ds_read_b128), the lane's 32 row values are split once per tile.
+template <int KH, int TG, int MODE, int NW, bool B6 = false>
 __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                           float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
   constexpr int WAVES = NW;
   extern __shared__ __align__(16) float w_lds[];   // [2 KH][C], then NW x [32][OS] result images
   constexpr int K = 2 * KH;
   const int tid = threadIdx.x;
-  for (int i = tid * 4; i < K * C; i += 64 * WAVES * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
+  static_assert(!B6 || (K % 16 == 0 && TG == 1), "B6: whole 16-k steps, one column tile per MFMA loop");
+  constexpr int KS = K / 16;                         // B6: k steps
+  const int w_floats = B6 ? (3 * K * C) / 2 : K * C; // LDS floats taken by the weight
+  if (B6) {
+    uint16_t* wb = reinterpret_cast<uint16_t*>(w_lds);
+    for (int i = tid * 2; i < K * C; i += 64 * WAVES * 2) {   // two consecutive columns of one k
+      const int k = i / C, c = i - k * C;
+      const float2 t = *reinterpret_cast<const float2*>(W + i);
+      uint32_t hi, mid, lo;
+      split3_pair(t.x, t.y, hi, mid, lo);
+      const int o = ((k >> 4) * C + c) * 16 + (k & 15);
+      wb[o] = (uint16_t)hi; wb[o + 16] = (uint16_t)(hi >> 16);
+      wb[KS * C * 16 + o] = (uint16_t)mid; wb[KS * C * 16 + o + 16] = (uint16_t)(mid >> 16);
+      wb[2 * KS * C * 16 + o] = (uint16_t)lo; wb[2 * KS * C * 16 + o + 16] = (uint16_t)(lo >> 16);
+    }
+  } else {
+    for (int i = tid * 4; i < K * C; i += 64 * WAVES * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
+  }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, half = lane >> 5;
-  float* img = w_lds + K * C + wave * 32 * OS;
+  float* img = w_lds + w_floats + wave * 32 * OS;
   const int er = lane >> 3, ec = 4 * (lane & 7);       // epilogue: rows 8 i + er, columns ec .. ec + 3 of a tile
   const bool has_res = MODE == 0 && ep.res != nullptr;
   const int64_t n_tiles = (R + 32 * WAVES - 1) / (32 * WAVES);
@@ -123,14 +168,29 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       }
     }
     const float* pb_any = (MODE == 1 ? (ep.b_off ? ep.b_off : (ep.b_diag ? ep.b_diag : W)) : (ep.bias ? ep.bias : W)) + ec;
-    const float* ap = A + row * lda + half * KH;
-    float a[KH];
+    float a[B6 ? 1 : KH];
+    u32x4 ah[B6 ? KS : 1], am[B6 ? KS : 1], al[B6 ? KS : 1];   // B6: the lane's B fragments, k = 16 ks + 8 half + (0..7)
+    if constexpr (B6) {
 #pragma unroll
-    for (int s = 0; s < KH; s += 4) {
-      const float4 t = *reinterpret_cast<const float4*>(ap + s);
-      a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
+      for (int ks = 0; ks < KS; ++ks) {
+        const float* ap = A + row * lda + 16 * ks + 8 * half;
+        const float4 t0 = *reinterpret_cast<const float4*>(ap), t1 = *reinterpret_cast<const float4*>(ap + 4);
+        uint32_t h, m, l;
+        split3_pair(t0.x, t0.y, h, m, l); ah[ks][0] = h; am[ks][0] = m; al[ks][0] = l;
+        split3_pair(t0.z, t0.w, h, m, l); ah[ks][1] = h; am[ks][1] = m; al[ks][1] = l;
+        split3_pair(t1.x, t1.y, h, m, l); ah[ks][2] = h; am[ks][2] = m; al[ks][2] = l;
+        split3_pair(t1.z, t1.w, h, m, l); ah[ks][3] = h; am[ks][3] = m; al[ks][3] = l;
+      }
+    } else {
+      const float* ap = A + row * lda + half * KH;
+#pragma unroll
+      for (int s = 0; s < KH; s += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(ap + s);
+        a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
+      }
     }
     const float* wl = w_lds + half * KH * C + j;
+    const u32x4* wq = reinterpret_cast<const u32x4*>(w_lds) + (j * 2 + half);   // B6: + ((plane * KS + ks) * C + n0) * 2
     // addends: TG == 1 requests a tile's addends in front of its own MFMA loop (one buffer); TG > 1 requests them one
     // tile ahead (two buffers)
     Addend cur, nxt;
@@ -142,12 +202,28 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       for (int t = 0; t < TG; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+      if constexpr (B6) {
 #pragma unroll
-      for (int s = 0; s < KH; ++s) {
+        for (int ks = 0; ks < KS; ++ks) {
+          const u32x4 wh = wq[((0 * KS + ks) * C + n0) * 2];
+          const u32x4 wm = wq[((1 * KS + ks) * C + n0) * 2];
+          const u32x4 wo = wq[((2 * KS + ks) * C + n0) * 2];
+          // small terms first
+          acc[0] = mfma_bf16(wo, ah[ks], acc[0]);
+          acc[0] = mfma_bf16(wh, al[ks], acc[0]);
+          acc[0] = mfma_bf16(wm, am[ks], acc[0]);
+          acc[0] = mfma_bf16(wm, ah[ks], acc[0]);
+          acc[0] = mfma_bf16(wh, am[ks], acc[0]);
+          acc[0] = mfma_bf16(wh, ah[ks], acc[0]);
+        }
+      } else {
 #pragma unroll
-        for (int t = 0; t < TG; ++t) {
-          const float b = wl[s * C + n0 + 32 * t];
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a[s], acc[t], 0, 0, 0);
+        for (int s = 0; s < KH; ++s) {
+#pragma unroll
+          for (int t = 0; t < TG; ++t) {
+            const float b = wl[s * C + n0 + 32 * t];
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(b, a[s], acc[t], 0, 0, 0);
+          }
         }
       }
 #pragma unroll
@@ -192,14 +268,14 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
   }
 }
 
-template <int KH, int TG, int MODE, int NW = 8>
+template <int KH, int TG, int MODE, int NW = 8, bool B6 = false>
 int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
            hipStream_t st) {
   constexpr int WAVES = NW;
-  const size_t lds = ((size_t)2 * KH * C + (size_t)WAVES * 32 * OS) * sizeof(float);
+  const size_t lds = ((size_t)(B6 ? 3 : 2) * KH * C + (size_t)WAVES * 32 * OS) * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit of a kernel is a per-process property of the function
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
@@ -208,8 +284,18 @@ int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, i
   // persistent workgroups: two per CU where the weight and the result images allow it
   const int per_cu = lds <= 78 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
-  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
+  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW, B6>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
   return hotk_launch_status();
+}
+
+bool gemm_f32() {
+  static const int v = [] { const char* e = getenv("HOTK_GEMM_F32"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+
+bool b6_narrow() {   // HOTK_GEMM_B6_NARROW=1: the K = 32 products in the split-bf16 form as well (A/B runs)
+  static const int v = [] { const char* e = getenv("HOTK_GEMM_B6_NARROW"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
 }
 
 template <int MODE>
@@ -217,9 +303,19 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
              const Epi& ep, hipStream_t st) {
   // gathered addends (MODE 1) are requested one 32-column tile ahead: with one tile per MFMA loop their latency hides
   // behind the whole loop
-  if (K == 64 && C % 96 == 0) return MODE == 1 ? launch<32, 1, MODE, HOTK_ENTRY_WAVES>(A, lda, W, Y, ldy, R, (int)C, ep, st)
-                                               : launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
-  if (K == 32 && C % 160 == 0) return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  if (K == 64 && C % 96 == 0) {
+    if (MODE == 1) {
+      // the split-bf16 form when its three weight planes fit in LDS beside the result images (HOTK_GEMM_F32=1: A/B runs)
+      const bool b6 = !gemm_f32() && ((size_t)3 * 32 * C + (size_t)HOTK_ENTRY_WAVES * 32 * OS) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+      return b6 ? launch<32, 1, MODE, HOTK_ENTRY_WAVES, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
+                : launch<32, 1, MODE, HOTK_ENTRY_WAVES>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+    }
+    return launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  }
+  if (K == 32 && C % 160 == 0) {
+    if (MODE == 0 && b6_narrow()) return launch<16, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+    return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  }
   if (K == 288 && C % 64 == 0) return launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 320 && C % 32 == 0) return launch<160, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   return HOTK_EUNSUPPORTED;

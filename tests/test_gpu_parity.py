@@ -384,6 +384,37 @@ def test_linear22_entry_gemm_matches_assemble_path():
     assert float(outs[0][0].view(-1, 288)[pad].abs().max()) == 0.0
 
 
+def test_linear22_entry_gemm_vs_fp64():
+    """hotk_linear22_entry_fwd through the C ABI against an fp64 statement of its contract
+    (off-diagonal: x2 W + yn[i][C:2C] + yn[j][2C:3C] + b_off; diagonal: yn[v][0:C] + b_diag; padding: 0).  At K = 64 the
+    products run as six bf16 MFMAs per 16 k on exact three-way bf16 splits of both operands (csrc/gemm.hip): the bar is
+    the fp32 one, 1e-5, and the observed error is that of an fp32 GEMM (~2e-7)."""
+    _lib, ops, *_ = _product()
+    from ctypes import c_void_p
+    g = torch.Generator().manual_seed(77)
+    R, K, C, Nn = 50021, 64, 288, 4001
+    x2 = torch.randn(R, K, generator=g).to(DEV)
+    W = (torch.randn(K, C, generator=g) * K ** -0.5).to(DEV)
+    yn = torch.randn(Nn, 3 * C, generator=g).to(DEV)
+    b_off, b_diag = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    kind = torch.randint(0, 3, (R,), generator=g).to(torch.uint8).to(DEV)
+    rn = torch.randint(0, Nn, (R,), generator=g).to(torch.int32).to(DEV)
+    cn = torch.randint(0, Nn, (R,), generator=g).to(torch.int32).to(DEV)
+    x2 = x2 * (kind == 2).unsqueeze(1)                       # the pair tensor is zero off the off-diagonal rows
+    rn = torch.where(kind == 0, torch.full_like(rn, -1), rn)  # padding rows carry node id -1 (plan)
+    cn = torch.where(kind == 0, torch.full_like(cn, -1), cn)
+    y = torch.empty(R, C, device=DEV)
+    _lib.call('hotk_linear22_entry_fwd', 0, _lib.p(x2), K, _lib.p(W), K, C, _lib.p(yn), 3 * C, _lib.p(kind), _lib.p(rn),
+              _lib.p(cn), _lib.p(b_off), _lib.p(b_diag), _lib.p(y), C, R, Nn)
+    ynd, rl, cl = yn.double(), rn.long().clamp_min(0), cn.long().clamp_min(0)
+    off = x2.double() @ W.double() + ynd[rl][:, C:2 * C] + ynd[cl][:, 2 * C:] + b_off.double()
+    dg = ynd[rl][:, :C] + b_diag.double()
+    ref = torch.where((kind == 2).unsqueeze(1), off, torch.where((kind == 1).unsqueeze(1), dg, torch.zeros_like(off)))
+    err = float((y.double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, err
+    assert float(y[kind == 0].abs().max()) == 0.0
+
+
 def _ba_case(n_graphs, seed):
     from oracle import hot_oracle as O
     rng = np.random.default_rng(seed)
