@@ -114,8 +114,11 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
   extern __shared__ __align__(16) float w_lds[];   // [2 KH][C], then NW x [32][OS] result images
   constexpr int K = 2 * KH;
   const int tid = threadIdx.x;
-  static_assert(!B6 || (K % 16 == 0 && TG == 1), "B6: whole 16-k steps, one column tile per MFMA loop");
   constexpr int KS = K / 16;                         // B6: k steps
+  // B6 with a wide input (K > 64): the row values are loaded and split per k step inside the MFMA loop (one step ahead)
+  // instead of being held for the whole tile, and the TG column tiles of a group share each split
+  constexpr bool STREAM = B6 && KS > 4;
+  static_assert(!B6 || (K % 16 == 0 && (STREAM || TG == 1)), "B6: whole 16-k steps; narrow inputs: one column tile per loop");
   const int w_floats = B6 ? (3 * K * C) / 2 : K * C; // LDS floats taken by the weight
   if (B6) {
     uint16_t* wb = reinterpret_cast<uint16_t*>(w_lds);
@@ -169,8 +172,10 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
     }
     const float* pb_any = (MODE == 1 ? (ep.b_off ? ep.b_off : (ep.b_diag ? ep.b_diag : W)) : (ep.bias ? ep.bias : W)) + ec;
     float a[B6 ? 1 : KH];
-    u32x4 ah[B6 ? KS : 1], am[B6 ? KS : 1], al[B6 ? KS : 1];   // B6: the lane's B fragments, k = 16 ks + 8 half + (0..7)
-    if constexpr (B6) {
+    constexpr int NF = (B6 && !STREAM) ? KS : 1;
+    u32x4 ah[NF], am[NF], al[NF];   // B6: the lane's B fragments, k = 16 ks + 8 half + (0..7)
+    if constexpr (STREAM) {
+    } else if constexpr (B6) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const float* ap = A + row * lda + 16 * ks + 8 * half;
@@ -202,7 +207,34 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       for (int t = 0; t < TG; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-      if constexpr (B6) {
+      if constexpr (STREAM) {
+        const float* ap = A + row * lda + 8 * half;
+        float4 r0 = *reinterpret_cast<const float4*>(ap), r1 = *reinterpret_cast<const float4*>(ap + 4);
+#pragma unroll 2
+        for (int ks = 0; ks < KS; ++ks) {
+          const int kn = ks + 1 < KS ? ks + 1 : ks;
+          const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * kn), q1 = *reinterpret_cast<const float4*>(ap + 16 * kn + 4);
+          u32x4 bh, bm, bl;
+          uint32_t h, m, l;
+          split3_pair(r0.x, r0.y, h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
+          split3_pair(r0.z, r0.w, h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
+          split3_pair(r1.x, r1.y, h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
+          split3_pair(r1.z, r1.w, h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
+#pragma unroll
+          for (int t = 0; t < TG; ++t) {
+            const u32x4 wh = wq[((0 * KS + ks) * C + n0 + 32 * t) * 2];
+            const u32x4 wm = wq[((1 * KS + ks) * C + n0 + 32 * t) * 2];
+            const u32x4 wo = wq[((2 * KS + ks) * C + n0 + 32 * t) * 2];
+            acc[t] = mfma_bf16(wo, bh, acc[t]);
+            acc[t] = mfma_bf16(wh, bl, acc[t]);
+            acc[t] = mfma_bf16(wm, bm, acc[t]);
+            acc[t] = mfma_bf16(wm, bh, acc[t]);
+            acc[t] = mfma_bf16(wh, bm, acc[t]);
+            acc[t] = mfma_bf16(wh, bh, acc[t]);
+          }
+          r0 = q0; r1 = q1;
+        }
+      } else if constexpr (B6) {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
           const u32x4 wh = wq[((0 * KS + ks) * C + n0) * 2];
@@ -316,8 +348,12 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
     if (MODE == 0 && b6_narrow()) return launch<16, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st);
     return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   }
-  if (K == 288 && C % 64 == 0) return launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
-  if (K == 320 && C % 32 == 0) return launch<160, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  // wide input, narrow output: split-bf16 form while the three weight planes fit in LDS beside the result images
+  const bool b6_fits = !gemm_f32() && ((size_t)3 * (K / 2) * C + (size_t)8 * 32 * OS) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+  if (K == 288 && C % 64 == 0) return b6_fits ? launch<144, 2, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
+                                              : launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  if (K == 320 && C % 32 == 0) return b6_fits ? launch<160, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
+                                              : launch<160, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   return HOTK_EUNSUPPORTED;
 }
 
