@@ -351,7 +351,9 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
       return b6 ? launch<32, 1, MODE, HOTK_ENTRY_WAVES, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
                 : launch<32, 1, MODE, HOTK_ENTRY_WAVES>(A, lda, W, Y, ldy, R, (int)C, ep, st);
     }
-    return launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+    const bool b6m0 = !gemm_f32() && ((size_t)3 * 32 * C + (size_t)8 * 32 * OS) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+    return b6m0 ? launch<32, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
+                : launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   }
   if (K == 32 && C % 160 == 0) {
     if (MODE == 0 && b6_narrow()) return launch<16, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st);
