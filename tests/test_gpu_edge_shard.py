@@ -177,3 +177,29 @@ def test_fused_one_large_graph_many_chunks(sharded):
     row_err = (gx1 - gx0).abs().amax(-1) / gx0.abs().max()
     assert float((row_err > 2e-5).float().mean()) <= 2e-3
     assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 1e-3
+
+
+def test_fused_phases_padded_batch():
+    """the phased core on a batch of two graphs of different sizes (padding node and entry rows: their kvn / nd0 / dd0
+    rows are never written or read) with a one-rank shard context, against the one-pass core"""
+    from hot_amd.batch import sparse as bs
+    from hot_amd.dist import ShardInfo
+    (nf1, ei1, ef1, _), (nf2, ei2, ef2, _) = _graph(seed=21, n=120, n_pairs=400), _graph(seed=22, n=75, n_pairs=150)
+    nf, ef = torch.cat([nf1, nf2]), torch.cat([ef1, ef2])
+    ei = torch.cat([ei1, ei2], dim=1)
+    res = []
+    for sharded in (False, True):
+        layer = _layer()
+        G = bs.make_batch_concatenated(nf.to(DEV), ei.to(DEV), ef.to(DEV), [120, 75], [ei1.size(1), ei2.size(1)])
+        assert G.plan.Ev != G.plan.R and G.plan.B == 2
+        if sharded:
+            G.plan.shard = ShardInfo(0, 1, (G.plan.kind != 0).to(torch.float32))
+        x = G.values.clone().requires_grad_(True)
+        y = layer(bs.batch_like(G, x, skip_masking=True))
+        y.values.square().sum().backward()
+        res.append((y.values.detach(), x.grad.clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}))
+    (y0, gx0, gp0), (y1, gx1, gp1) = res
+    assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 2e-5
+    assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 2e-5
+    pad = (G.plan.kind == 0).view(-1)
+    assert float(y1.view(-1, y1.size(-1))[pad].abs().max()) == 0.0
