@@ -13,10 +13,50 @@
 // launches over the two column halves, the second adding its part of dx to the first's (every byte of g is still read
 // once; dx, 1/10 of g, is re-read once).
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+// fp32 products as six bf16 MFMAs on exact three-way bf16 splits of both operands (see csrc/gemm.hip)
+__device__ __forceinline__ uint32_t lb_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float lb_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+__device__ __forceinline__ void lb_split3_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t h0 = lb_f2u(x0) & 0xffff0000u, h1 = lb_f2u(x1) & 0xffff0000u;
+  const float r0 = x0 - lb_u2f(h0), r1 = x1 - lb_u2f(h1);
+  const uint32_t m0 = lb_f2u(r0) & 0xffff0000u, m1 = lb_f2u(r1) & 0xffff0000u;
+  const float s0 = r0 - lb_u2f(m0), s1 = r1 - lb_u2f(m1);
+  hi = (h0 >> 16) | h1;
+  mid = (m0 >> 16) | m1;
+  lo = (lb_f2u(s0) >> 16) | (lb_f2u(s1) & 0xffff0000u);
+}
+struct Planes { u32x4 h, m, l; };
+__device__ __forceinline__ Planes lb_split8(const float (&v)[8]) {
+  Planes p;
+  uint32_t h, m, l;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    lb_split3_pair(v[2 * q], v[2 * q + 1], h, m, l);
+    p.h[q] = h; p.m[q] = m; p.l[q] = l;
+  }
+  return p;
+}
+__device__ __forceinline__ f32x16 lb_mfma(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// acc += A . B with A = ah + am + al, B = bh + bm + bl (the three products below 2^-24 of the result dropped)
+__device__ __forceinline__ f32x16 lb_mfma6(const Planes& a, const Planes& b, f32x16 c) {
+  c = lb_mfma(a.l, b.h, c);
+  c = lb_mfma(a.h, b.l, c);
+  c = lb_mfma(a.m, b.m, c);
+  c = lb_mfma(a.m, b.h, c);
+  c = lb_mfma(a.h, b.m, c);
+  c = lb_mfma(a.h, b.h, c);
+  return c;
+}
 
 constexpr int LB_K = 32;         // input width
 constexpr int LB_WAVES = 8;      // waves per workgroup (one LDS copy of W)
@@ -29,7 +69,9 @@ __device__ __forceinline__ void lb_fence() {
 }
 
 // columns [c_lo, c_lo + 32 NCH) of g / W; Ctot = full width (row stride of W and of the partial blocks)
-template <int NCH, bool WANT_DX>
+// B6: both products as bf16 MFMAs (32x32x16) on split operands; W then sits in LDS as three bf16 planes
+// [plane][chunk][k step][k (32)][16 c] (a lane's A fragment = one ds_read_b128), behind the fp32 copy's place
+template <int NCH, bool WANT_DX, bool B6 = false>
 __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
                                                              int64_t ldx, const float* __restrict__ W, float* __restrict__ DX,
                                                              int64_t lddx, float* __restrict__ partial, int64_t R, int c_lo,
@@ -37,12 +79,27 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
   constexpr int C = 32 * NCH;
   constexpr int CS = C + 2;      // W row stride in LDS: 2 or 34 mod 64 -> bank (2 or 34) k + c parity, all 64 distinct
   extern __shared__ __align__(16) float lds[];
-  float* w_lds = lds;                                  // [32][CS]
+  float* w_lds = lds;                                  // [32][CS]   (B6: 3 x NCH x 2 x 32 x 16 bf16 = 1.5 x 32 x C floats)
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, j = lane & 31, half = lane >> 5;
-  float* gt = lds + LB_K * CS + wave * (32 * LB_GS + 32 * LB_OS);   // staged g chunk [32][GS]
+  constexpr int WF = B6 ? (3 * LB_K * C) / 2 : LB_K * CS;   // floats of LDS taken by W
+  float* gt = lds + WF + wave * (32 * LB_GS + 32 * LB_OS);   // staged g chunk [32][GS]
   float* xt = gt + 32 * LB_GS;                                        // staged x tile / dx image [32][OS]
   if (WANT_DX) {
-    for (int i = tid; i < LB_K * C; i += 64 * LB_WAVES) w_lds[(i / C) * CS + (i % C)] = W[(i / C) * Ctot + c_lo + (i % C)];
+    if constexpr (B6) {
+      uint16_t* wb = reinterpret_cast<uint16_t*>(lds);
+      constexpr int PL = NCH * 2 * 32 * 16;            // bf16 elements per plane
+      for (int i = tid; i < LB_K * (C / 2); i += 64 * LB_WAVES) {   // two consecutive columns of one k
+        const int k = i / (C / 2), c = 2 * (i - k * (C / 2));
+        uint32_t hi, mid, lo;
+        lb_split3_pair(W[k * Ctot + c_lo + c], W[k * Ctot + c_lo + c + 1], hi, mid, lo);
+        const int o = (((c >> 5) * 2 + ((c >> 4) & 1)) * 32 + k) * 16 + (c & 15);
+        wb[o] = (uint16_t)hi; wb[o + 1] = (uint16_t)(hi >> 16);
+        wb[PL + o] = (uint16_t)mid; wb[PL + o + 1] = (uint16_t)(mid >> 16);
+        wb[2 * PL + o] = (uint16_t)lo; wb[2 * PL + o + 1] = (uint16_t)(lo >> 16);
+      }
+    } else {
+      for (int i = tid; i < LB_K * C; i += 64 * LB_WAVES) w_lds[(i / C) * CS + (i % C)] = W[(i / C) * Ctot + c_lo + (i % C)];
+    }
     __syncthreads();
   }
   f32x16 dw[NCH];
@@ -75,9 +132,20 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
       *reinterpret_cast<float4*>(xt + (8 * i + lr) * LB_OS + lc) = t;
     }
     lb_fence();
-    float xa[16];
+    float xa[B6 ? 1 : 16];
+    Planes xp[B6 ? 2 : 1];   // B6: A fragments of dW, x[row 16 ks + 8 half + e][k = j]
+    if constexpr (B6) {
 #pragma unroll
-    for (int s = 0; s < 16; ++s) xa[s] = xt[(2 * s + half) * LB_OS + j];
+      for (int ks = 0; ks < 2; ++ks) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = xt[(16 * ks + 8 * half + e) * LB_OS + j];
+        xp[ks] = lb_split8(v);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) xa[s] = xt[(2 * s + half) * LB_OS + j];
+    }
     f32x16 dxa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
@@ -98,15 +166,46 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
 #pragma unroll
         for (int i = 0; i < 4; ++i) nx[i] = live[i] ? *reinterpret_cast<const float4*>(grow[i] + 32 * (ch + 1)) : z4;
       }
-      const float* wl = w_lds + j * CS + 32 * ch + half;
+      if constexpr (B6) {
+        const u32x4* wq = reinterpret_cast<const u32x4*>(lds);
+        constexpr int PLQ = NCH * 2 * 32 * 2;            // u32x4 (8 bf16) per plane
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const float gb = gt[(2 * s + half) * LB_GS + j];     // g[row 2s + half][c = j]
-        dw[ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], gb, dw[ch], 0, 0, 0);
-        dbp[ch] += gb;
-        if (WANT_DX) {
-          const float gr = gt[j * LB_GS + 2 * s + half];      // g[row j][c = 2s + half]
-          dxa = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[2 * s], gr, dxa, 0, 0, 0);
+        for (int ks = 0; ks < 2; ++ks) {
+          // dW: B fragment g[row 16 ks + 8 half + e][c = j]; the same values feed the column sums
+          float v[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            v[e] = gt[(16 * ks + 8 * half + e) * LB_GS + j];
+            dbp[ch] += v[e];
+          }
+          const Planes gb = lb_split8(v);
+          dw[ch] = lb_mfma6(xp[ks], gb, dw[ch]);
+          if (WANT_DX) {
+            // dx: A fragment W[k = j][32 ch + 16 ks + 8 half + e], B fragment g[row j][16 ks + 8 half + e]
+            float u[8];
+#pragma unroll
+            for (int e = 0; e < 8; e += 2) {
+              const float2 t = *reinterpret_cast<const float2*>(gt + j * LB_GS + 16 * ks + 8 * half + e);
+              u[e] = t.x; u[e + 1] = t.y;
+            }
+            const Planes gr = lb_split8(u);
+            const int wo = ((ch * 2 + ks) * 32 + j) * 2 + half;
+            Planes wp;
+            wp.h = wq[wo]; wp.m = wq[PLQ + wo]; wp.l = wq[2 * PLQ + wo];
+            dxa = lb_mfma6(wp, gr, dxa);
+          }
+        }
+      } else {
+        const float* wl = w_lds + j * CS + 32 * ch + half;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+          const float gb = gt[(2 * s + half) * LB_GS + j];     // g[row 2s + half][c = j]
+          dw[ch] = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[s], gb, dw[ch], 0, 0, 0);
+          dbp[ch] += gb;
+          if (WANT_DX) {
+            const float gr = gt[j * LB_GS + 2 * s + half];      // g[row j][c = 2s + half]
+            dxa = __builtin_amdgcn_mfma_f32_32x32x2f32(wl[2 * s], gr, dxa, 0, 0, 0);
+          }
         }
       }
     }
@@ -145,20 +244,36 @@ unsigned lb_grid(int64_t R) {
   return (unsigned)(n_tiles < 256 ? (n_tiles < 1 ? 1 : n_tiles) : 256);
 }
 
-template <int NCH, bool WANT_DX>
-int lb_launch(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
+// HOTK_LINBWD_B6=1 selects the split-bf16 form.  Measured at 10 M rows x 320 and NOT adopted: 5.5 ms against 5.0 ms for
+// the fp32 MFMAs -- here every staged gradient value is split twice (once per product orientation: 32 values and ~10
+// VALU instructions each per lane and chunk), which costs more than the 1 280 matrix cycles per chunk it saves; the
+// thin GEMMs split a value once per 288 output columns.
+bool lb_f32() {
+  static const int v = [] { const char* e = getenv("HOTK_LINBWD_B6"); return (e && e[0] == '1') ? 0 : 1; }();
+  return v != 0;
+}
+
+template <int NCH, bool WANT_DX, bool B6>
+int lb_launch_t(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
               float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
   constexpr int C = 32 * NCH;
-  const size_t lds = ((size_t)LB_K * (C + 2) + (size_t)LB_WAVES * (32 * LB_GS + 32 * LB_OS)) * sizeof(float);
+  const size_t lds = ((size_t)(B6 ? (3 * LB_K * C) / 2 : LB_K * (C + 2)) + (size_t)LB_WAVES * (32 * LB_GS + 32 * LB_OS)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_linear_bwd<NCH, WANT_DX>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_linear_bwd<NCH, WANT_DX, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_linear_bwd<NCH, WANT_DX>), dim3(lb_grid(R)), dim3(64 * LB_WAVES), lds, st, G, ldg, X, ldx, W, DX, lddx, partial, R,
+  hipLaunchKernelGGL((k_linear_bwd<NCH, WANT_DX, B6>), dim3(lb_grid(R)), dim3(64 * LB_WAVES), lds, st, G, ldg, X, ldx, W, DX, lddx, partial, R,
                      c_lo, Ctot, add_dx);
   return hotk_launch_status();
+}
+
+template <int NCH, bool WANT_DX>
+int lb_launch(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
+              float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
+  return lb_f32() ? lb_launch_t<NCH, WANT_DX, false>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st)
+                  : lb_launch_t<NCH, WANT_DX, true>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
 }
 
 }  // namespace
