@@ -13,6 +13,8 @@ constexpr int AT_CT = 9;  // channels accumulated per thread and pass: c = 8 val
 
 // work item = (segment, chunk, channel tile, feature); consecutive lanes -> consecutive features, so the
 // key row is read as contiguous 256-B pieces and the value channels are wave-broadcast loads.
+// C8: c == 8 with 16-byte aligned value rows -- the head's 8 values arrive as two 16-byte loads instead of 8 scalar ones
+template <bool C8>
 __global__ __launch_bounds__(AT_THREADS) void k_seg_outer_sum(
     const float* __restrict__ K, int64_t ld_k, const int32_t* __restrict__ kidx, const float* __restrict__ V,
     int64_t ld_v, const int32_t* __restrict__ vidx, const float* __restrict__ aug, int64_t ld_aug,
@@ -43,6 +45,18 @@ __global__ __launch_bounds__(AT_THREADS) void k_seg_outer_sum(
       const float kv = K[kr * ld_k + f];
       int64_t vr = vidx ? (int64_t)vidx[r] : r;
       const float* vp = V + vr * ld_v + hh * c;
+      if (C8) {
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (vr >= 0) {
+          v0 = *reinterpret_cast<const float4*>(vp);
+          v1 = *reinterpret_cast<const float4*>(vp + 4);
+        }
+        const float va = aug ? aug[r * ld_aug + hh] : 1.f;
+        acc[0] = fmaf(kv, v0.x, acc[0]); acc[1] = fmaf(kv, v0.y, acc[1]); acc[2] = fmaf(kv, v0.z, acc[2]);
+        acc[3] = fmaf(kv, v0.w, acc[3]); acc[4] = fmaf(kv, v1.x, acc[4]); acc[5] = fmaf(kv, v1.y, acc[5]);
+        acc[6] = fmaf(kv, v1.z, acc[6]); acc[7] = fmaf(kv, v1.w, acc[7]); acc[8] = fmaf(kv, va, acc[8]);
+        continue;
+      }
 #pragma unroll
       for (int k = 0; k < AT_CT; ++k) {
         int chn = c0 + k;
@@ -234,9 +248,16 @@ extern "C" int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* k
   int n_tile = (c + 1 + AT_CT - 1) / AT_CT;
   int Fp = (HH * m + 63) & ~63;
   int64_t work = n_seg * n_chunk * n_tile * Fp;
-  hipLaunchKernelGGL(k_seg_outer_sum, dim3(hotk_grid(work, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
-                     (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug, ld_aug, seg_begin, seg_end, perm, KV,
-                     n_seg, HH, m, c, n_chunk, n_tile);
+  static_assert(AT_CT == 9, "the C8 form keeps 8 values + the normaliser in one tile");
+  const bool c8 = c == 8 && (ld_v & 3) == 0 && hotk_aligned16(V);
+  if (c8)
+    hipLaunchKernelGGL(k_seg_outer_sum<true>, dim3(hotk_grid(work, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
+                       (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug, ld_aug, seg_begin, seg_end, perm, KV,
+                       n_seg, HH, m, c, n_chunk, n_tile);
+  else
+    hipLaunchKernelGGL(k_seg_outer_sum<false>, dim3(hotk_grid(work, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
+                       (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug, ld_aug, seg_begin, seg_end, perm, KV,
+                       n_seg, HH, m, c, n_chunk, n_tile);
   return hotk_launch_status();
 }
 
