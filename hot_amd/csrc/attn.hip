@@ -90,6 +90,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_contract(
     int normalize) {
   const int F = HH * m, c1 = c + 1, W = HH * c;
   const int64_t total = n * W;
+  const bool q4 = (m & 3) == 0 && (ld_q & 3) == 0 && (((uintptr_t)Q) & 15u) == 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = t / W;
     int w = (int)(t - r * W);
@@ -103,10 +104,21 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_contract(
       const float* q = Q + qr * ld_q + hh * m;
       const float* kv = KV + ((int64_t)s * F + hh * m) * c1;
       float num = 0.f, den = 0.f;
-      for (int mm = 0; mm < m; ++mm) {
-        float qv = q[mm];
-        num = fmaf(qv, kv[mm * c1 + chn], num);
-        den = fmaf(qv, kv[mm * c1 + c], den);
+      if (q4) {   // m % 4 == 0, 16-byte aligned rows: the query slice as vector loads (same fmaf order)
+        for (int mm = 0; mm < m; mm += 4) {
+          const float4 qv = *reinterpret_cast<const float4*>(q + mm);
+          const float* k0 = kv + mm * c1;
+          num = fmaf(qv.x, k0[chn], num);          den = fmaf(qv.x, k0[c], den);
+          num = fmaf(qv.y, k0[c1 + chn], num);     den = fmaf(qv.y, k0[c1 + c], den);
+          num = fmaf(qv.z, k0[2 * c1 + chn], num); den = fmaf(qv.z, k0[2 * c1 + c], den);
+          num = fmaf(qv.w, k0[3 * c1 + chn], num); den = fmaf(qv.w, k0[3 * c1 + c], den);
+        }
+      } else {
+        for (int mm = 0; mm < m; ++mm) {
+          float qv = q[mm];
+          num = fmaf(qv, kv[mm * c1 + chn], num);
+          den = fmaf(qv, kv[mm * c1 + c], den);
+        }
       }
       if (normalize) {
         if (den == 0.f) den = 1e-5f;
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
     int c) {
   const int F = HH * m, c1 = c + 1;
   const int64_t total = n * F;
+  const bool x8 = c == 8 && (ld_x & 3) == 0 && (((uintptr_t)X) & 15u) == 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = t / F;
     int f = (int)(t - r * F);
@@ -223,7 +236,13 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
       int64_t xr = xidx ? (int64_t)xidx[r] : r;
       if (xr >= 0) {
         const float* xp = X + xr * ld_x + hh * c;
-        for (int chn = 0; chn < c; ++chn) o = fmaf(kv[chn], xp[chn], o);
+        if (x8) {   // c == 8, 16-byte aligned rows: two vector loads (same fmaf order)
+          const float4 x0 = *reinterpret_cast<const float4*>(xp), x1 = *reinterpret_cast<const float4*>(xp + 4);
+          o = fmaf(kv[0], x0.x, o); o = fmaf(kv[1], x0.y, o); o = fmaf(kv[2], x0.z, o); o = fmaf(kv[3], x0.w, o);
+          o = fmaf(kv[4], x1.x, o); o = fmaf(kv[5], x1.y, o); o = fmaf(kv[6], x1.z, o); o = fmaf(kv[7], x1.w, o);
+        } else {
+          for (int chn = 0; chn < c; ++chn) o = fmaf(kv[chn], xp[chn], o);
+        }
       }
       o = fmaf(kv[c], XA ? XA[r * ld_xa + hh] : 1.f, o);
     }
