@@ -164,6 +164,16 @@ def require_device(t: torch.Tensor, what='tensor'):
                         f'There is no CPU path: move the Batch / module to the GPU.')
 
 
+def require_unsharded(plan, what):
+    """Edge-shard mode (hot_amd.dist.shard_graph, plan.shard) is implemented for the kernel-attention sums only.  Ops whose
+    sums over ENTRIES would be partial on a rank (and are not all-reduced yet) refuse to run instead of returning this
+    rank's partial result."""
+    shard = getattr(plan, 'shard', None)
+    if shard is not None and shard.world > 1:
+        raise HotkError(f'{what} is not available in edge-shard mode (world {shard.world}): its sums over entries would '
+                        f'cover this rank\'s shard only; see DESIGN.md section 6')
+
+
 def stream_ptr():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 

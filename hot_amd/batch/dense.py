@@ -15,23 +15,19 @@ from . import sparse as S
 
 
 class Batch(object):
-    A: torch.Tensor
-    n_nodes: list
-    device: torch.device
-    mask: torch.BoolTensor
-    order: int
+    """dense minibatch: A [B, N, D] (sets, order 1) or [B, N, N, D] (graphs, order 2), n_nodes python list, mask [B, N(, N)]
+    marking the valid positions"""
 
     def __init__(self, A: torch.Tensor, n_nodes: list, mask: torch.BoolTensor = None, skip_masking: bool = False):
-        """a mini-batch of dense (hyper)graphs: A [B, N^k, D], n_nodes python list, mask [B, N^k]"""
-        self.A = A
-        self.n_nodes = n_nodes
-        self.device = self.A.device
-        self.order = len(A.size()) - 2
-        assert self.order != 0, "zeroth-order data (N x D batched features) is expected to be handled separately"
-        assert self.order in (1, 2), "we currently support dense batching up to second order"
-        self.mask = self.get_mask() if mask is None else mask
-        assert self.mask.size(1) == max(n_nodes)
-        assert self.mask.size() == A.size()[:-1]
+        order = A.dim() - 2
+        if order == 0:
+            raise AssertionError('zeroth-order data (plain [B, D] features) is handled as a tensor, not a Batch')
+        if order not in (1, 2):
+            raise AssertionError('dense batching is supported up to second order')
+        self.A, self.n_nodes, self.device, self.order = A, n_nodes, A.device, order
+        self.mask = mask if mask is not None else self.get_mask()
+        if self.mask.size(1) != max(n_nodes) or self.mask.shape != A.shape[:-1]:
+            raise AssertionError(f'mask {tuple(self.mask.shape)} does not describe A {tuple(A.shape)} / n_nodes')
         self._plan = None
         if not skip_masking:
             self.apply_mask(0)
@@ -40,22 +36,19 @@ class Batch(object):
         return f"Batch(A {list(self.A.size())})"
 
     def to(self, device: Union[str, torch.device]) -> 'Batch':
-        self.A = self.A.to(device)
-        self.mask = self.mask.to(device)
-        if self._plan is not None and self._plan.device != self.A.device:
-            self._plan = None
+        self.A, self.mask = self.A.to(device), self.mask.to(device)
         self.device = self.A.device
+        if self._plan is not None and self._plan.device != self.device:
+            self._plan = None
         return self
 
     @torch.no_grad()
     def get_mask(self) -> torch.BoolTensor:
-        node_mask = get_mask(torch.tensor(self.n_nodes, dtype=torch.long, device=self.device))  # [B, N]
-        if self.order == 1:
-            return node_mask
-        return node_mask.unsqueeze(1) & node_mask.unsqueeze(2)  # [B, N, N]
+        """valid nodes [B, N]; for order 2 the outer product of that with itself [B, N, N]"""
+        valid = get_mask(torch.as_tensor(self.n_nodes, dtype=torch.long, device=self.device))
+        return valid if self.order == 1 else valid[:, :, None] & valid[:, None, :]
 
     def apply_mask(self, value=0.) -> None:
-        # mask out invalid tensor elements
         self.A = masked_fill(self.A, self.mask, value)
 
     @property
@@ -104,28 +97,26 @@ def from_sparse_view(G: Batch, H: S.Batch, order: int) -> Batch:
 
 
 def batch_like(G: Batch, A: torch.Tensor, skip_masking=False) -> Batch:
-    # only substitute A
+    """G's node counts and mask around other values"""
     return _carry(G, Batch(A, G.n_nodes, G.mask, skip_masking))
 
 
 def t(G: Batch) -> Batch:
-    # transpose
+    """swap the two node axes (a view)"""
     assert G.order == 2
     return _carry(G, Batch(G.A.transpose(2, 1), G.n_nodes, G.mask, skip_masking=True))
 
 
 def nd(G: Batch) -> Batch:
-    # get non-diagonals
+    """off-diagonal part"""
     assert G.order == 2
     H = S.nd(sparse_view(G))
     return from_sparse_view(G, H, 2)
 
 
 def d(G: Batch, mask: torch.Tensor = None) -> Batch:
-    # get diagonals
-    assert G.order == 2
-    if mask is not None:
-        assert len(mask.size()) == 2
+    """diagonal as an order-1 batch"""
+    assert G.order == 2 and (mask is None or mask.dim() == 2)
     H = S.d(sparse_view(G))
     out = Batch(H.values, G.n_nodes, mask, skip_masking=True)
     out._plan = G._plan
@@ -133,10 +124,8 @@ def d(G: Batch, mask: torch.Tensor = None) -> Batch:
 
 
 def v2d(G: Batch, mask: torch.Tensor = None) -> Batch:
-    # vectors to diagonal matrices
-    assert G.order == 1
-    if mask is not None:
-        assert len(mask.size()) == 3
+    """order-1 values on the diagonal of an order-2 batch, zero elsewhere"""
+    assert G.order == 1 and (mask is None or mask.dim() == 3)
     plan = G.plan
     Sv = sparse_view(G)
     carrier = S.Batch.__new__(S.Batch)
@@ -150,19 +139,16 @@ def v2d(G: Batch, mask: torch.Tensor = None) -> Batch:
 
 
 def apply(G: Union[torch.Tensor, Batch], f: Callable[[torch.Tensor], torch.Tensor], skip_masking=False) -> Union[torch.Tensor, Batch]:
-    if isinstance(G, torch.Tensor):
-        return f(G)
-    return _carry(G, Batch(f(G.A), G.n_nodes, G.mask, skip_masking))
+    """f on the values of a batch (or on a plain tensor)"""
+    return _carry(G, Batch(f(G.A), G.n_nodes, G.mask, skip_masking)) if isinstance(G, Batch) else f(G)
 
 
 def add_batch(G1: Union[torch.Tensor, Batch], G2: Union[torch.Tensor, Batch]) -> Union[torch.Tensor, Batch]:
-    # add features of two batched graphs with identical edge structures
-    if isinstance(G1, Batch) and isinstance(G2, Batch):
-        assert G1.order == G2.order
-        assert G1.n_nodes == G2.n_nodes
-        assert G1.A.size() == G2.A.size()
+    """sum of two batches of the same shape and node counts (or of two equally shaped tensors)"""
+    pair = (isinstance(G1, Batch), isinstance(G2, Batch))
+    if pair == (True, True):
+        same = G1.order == G2.order and G1.n_nodes == G2.n_nodes and G1.A.size() == G2.A.size()
+        assert same, 'add_batch: the two batches do not share their structure'
         return _carry(G1, Batch(G1.A + G2.A, G1.n_nodes, G1.mask, skip_masking=True))
-    else:
-        assert isinstance(G1, torch.Tensor) and isinstance(G2, torch.Tensor)
-        assert G1.size() == G2.size()
-        return G1 + G2
+    assert pair == (False, False) and G1.size() == G2.size(), 'add_batch: two batches or two equally shaped tensors'
+    return G1 + G2

@@ -10,52 +10,52 @@ from ..utils.set import get_mask, masked_fill
 from ..plan import Plan, NodePlan
 
 
+def _size_mask(sizes, device):
+    return get_mask(torch.as_tensor(sizes, dtype=torch.long, device=device))
+
+
 class Batch(object):
-    indices: Union[None, torch.LongTensor]
-    values: torch.Tensor
-    n_nodes: list
-    n_edges: Union[None, list]
-    device: torch.device
-    mask: torch.BoolTensor
-    node_mask: torch.BoolTensor
-    order: int
-    t_indices: Union[None, torch.LongTensor]
-    t_mask: Union[None, torch.BoolTensor]
-    node_ofs: torch.LongTensor
+    """A minibatch of graphs as padded entry rows.  Fields (names fixed by the reference interface):
+    indices [B,|E|,2] int64 or None (order 1), values [B,|E|,D], n_nodes / n_edges python lists (n_edges counts diagonal
+    AND off-diagonal entries), mask [B,|E|], node_mask [B,N], order, t_indices / t_mask (transpose map), node_ofs, device."""
 
     def __init__(self, indices: Union[None, torch.LongTensor], values: torch.Tensor,
                  n_nodes: list, n_edges: Union[None, list], mask: torch.BoolTensor = None, skip_masking: bool = False,
                  t_indices=None, t_mask=None, node_mask: torch.BoolTensor = None, node_ofs: torch.LongTensor = None):
-        """a mini-batch of sparse graphs: indices [B,|E|,2] long (or None for order 1), values [B,|E|,D],
-        n_nodes / n_edges python lists (n_edges counts diagonal + off-diagonal entries)."""
-        self.indices = indices
-        self.values = values
-        self.n_nodes = n_nodes
-        self.n_edges = n_edges
-        self.device = values.device
-        self.order = 1 if indices is None else indices.size(-1)
-        assert self.order in (1, 2)
-        self.node_mask = get_mask(torch.tensor(n_nodes, dtype=torch.long, device=self.device)) if node_mask is None else node_mask
-        if self.order == 1:
+        dev = values.device
+        order = 1 if indices is None else indices.size(-1)
+        if order not in (1, 2):
+            raise AssertionError(f'order-{order} batches are not supported')
+        self.indices, self.values, self.n_nodes, self.n_edges = indices, values, n_nodes, n_edges
+        self.device, self.order = dev, order
+        self.node_mask = node_mask if node_mask is not None else _size_mask(n_nodes, dev)
+        if order == 1:
             self.mask = self.node_mask
         else:
-            self.mask = get_mask(torch.tensor(n_edges, dtype=torch.long, device=self.device)) if mask is None else mask
+            self.mask = mask if mask is not None else _size_mask(n_edges, dev)
         self._plan = None
+        # zero-filling of invalid rows happens on the device (HIP kernel); a host-side batch remembers that it is due
         self._pending_mask = False
         if not skip_masking:
-            if self.values.is_cuda:
-                self.apply_mask(0)
-            else:
-                self._pending_mask = True   # applied by the HIP kernel when the batch reaches the device
-        if self.order == 2 and t_indices is None and t_mask is None:
-            if self.values.is_cuda:
-                plan = self.plan
-                self.t_indices, self.t_mask = plan.t_indices, plan.t_mask
-            else:
-                self.t_indices, self.t_mask = None, None    # built by K1 in .to(device)
+            self._mask_now_or_later()
+        have_map = not (t_indices is None and t_mask is None)
+        self.t_indices, self.t_mask = (t_indices, t_mask) if (have_map or order == 1) else self._transpose_map()
+        if node_ofs is None:
+            starts = np.cumsum([0] + list(n_nodes[:-1]))
+            node_ofs = torch.tensor(starts, dtype=torch.long, device=dev)
+        self.node_ofs = node_ofs
+
+    def _mask_now_or_later(self):
+        if self.values.is_cuda:
+            self.apply_mask(0)
         else:
-            self.t_indices, self.t_mask = t_indices, t_mask
-        self.node_ofs = torch.tensor(np.cumsum([0] + self.n_nodes[:-1]), dtype=torch.long, device=self.device) if node_ofs is None else node_ofs
+            self._pending_mask = True
+
+    def _transpose_map(self):
+        """(t_indices, t_mask) from kernel K1 once the batch lives on the device; (None, None) until then"""
+        if not self.values.is_cuda:
+            return None, None
+        return self.plan.t_indices, self.plan.t_mask
 
     def __repr__(self):
         i = None if self.indices is None else list(self.indices.size())
@@ -72,28 +72,24 @@ class Batch(object):
         return self._plan
 
     def to(self, device: Union[str, torch.device]) -> 'Batch':
-        if self.indices is not None:
-            self.indices = self.indices.to(device)
-            if self.t_indices is not None:
-                self.t_indices = self.t_indices.to(device)
-                self.t_mask = self.t_mask.to(device)
-        self.values = self.values.to(device)
-        self.mask = self.mask.to(device)
-        self.node_mask = self.node_mask.to(device)
-        self.node_ofs = self.node_ofs.to(device)
-        if self._plan is not None and self._plan.device != self.values.device:
-            self._plan = None
+        """move in place and return self (the reference's behaviour); the plan is rebuilt on the new device"""
+        for name in ('indices', 't_indices', 't_mask', 'values', 'mask', 'node_mask', 'node_ofs'):
+            held = getattr(self, name)
+            if held is not None:
+                setattr(self, name, held.to(device))
         self.device = self.values.device
+        if self._plan is not None and self._plan.device != self.device:
+            self._plan = None
         if self.values.is_cuda:
             if self._pending_mask:
-                self.apply_mask(0)
                 self._pending_mask = False
+                self.apply_mask(0)
             if self.order == 2 and self.t_indices is None:
-                self.t_indices, self.t_mask = self.plan.t_indices, self.plan.t_mask
+                self.t_indices, self.t_mask = self._transpose_map()
         return self
 
     def apply_mask(self, value=0.) -> None:
-        # mask out invalid tensor elements (indices are assumed well-masked already, as in the reference)
+        """overwrite the rows outside `mask` (the index tensors are taken to be clean already)"""
         self.values = masked_fill(self.values, self.mask, value)
 
 
@@ -103,66 +99,60 @@ def _carry(G: Batch, H: Batch) -> Batch:
 
 
 def batch_like(G: Batch, values: torch.Tensor, skip_masking=False) -> Batch:
-    # only substitute values
+    """G with other values: shares every index / mask tensor and the plan, builds nothing"""
     H = Batch.__new__(Batch)
-    H.indices, H.values, H.n_nodes, H.n_edges = G.indices, values, G.n_nodes, G.n_edges
-    H.device, H.order = values.device, G.order
-    H.mask, H.node_mask = G.mask, G.node_mask
-    H.t_indices, H.t_mask, H.node_ofs = G.t_indices, G.t_mask, G.node_ofs
-    H._plan, H._pending_mask = G._plan, False
+    H.__dict__.update(G.__dict__)
+    H.values, H.device, H._pending_mask = values, values.device, False
     if not skip_masking:
-        if values.is_cuda:
-            H.apply_mask(0)
-        else:
-            H._pending_mask = True
+        H._mask_now_or_later()
     return H
 
 
+def _order2(G: Batch) -> Batch:
+    if G.order != 2:
+        raise AssertionError('an order-2 batch is expected')
+    return G
+
+
 def t(G: Batch) -> Batch:
-    # transpose
-    assert G.order == 2
-    v_t = do_transpose(G.values, G.t_indices, G.t_mask, G.plan)
-    return batch_like(G, v_t, skip_masking=True)
+    """values of the transposed entries: row (i,j) receives the row of (j,i), zero where (j,i) is absent"""
+    _order2(G)
+    return batch_like(G, do_transpose(G.values, G.t_indices, G.t_mask, G.plan), skip_masking=True)
 
 
 def nd(G: Batch) -> Batch:
-    # get non-diagonals
-    assert G.order == 2
-    v_nd = get_nondiag(G.plan, G.values)
-    return batch_like(G, v_nd, skip_masking=True)
+    """off-diagonal part (diagonal rows zeroed)"""
+    _order2(G)
+    return batch_like(G, get_nondiag(G.plan, G.values), skip_masking=True)
 
 
 def d(G: Batch) -> Batch:
-    # get diagonals
-    assert G.order == 2
-    v_d = get_diag(G.plan, G.values)
-    H = Batch(None, v_d, G.n_nodes, None, G.node_mask, True, G.t_indices, G.t_mask, G.node_mask, G.node_ofs)
+    """diagonal rows as an order-1 batch [B, N, D]"""
+    _order2(G)
+    H = Batch(None, get_diag(G.plan, G.values), G.n_nodes, None, G.node_mask, True, G.t_indices, G.t_mask, G.node_mask,
+              G.node_ofs)
     return _carry(G, H)
 
 
 def v2d(G: Batch, values: Batch) -> Batch:
-    # vectors to diagonal matrices
-    v_d = to_diag(G.plan, values.values)
-    return batch_like(G, v_d, skip_masking=True)
+    """order-1 values placed on the diagonal rows of G's index set, zero elsewhere"""
+    return batch_like(G, to_diag(G.plan, values.values), skip_masking=True)
 
 
 def apply(G: Union[torch.Tensor, Batch], f: Callable[[torch.Tensor], torch.Tensor], skip_masking=False) -> Union[torch.Tensor, Batch]:
-    if isinstance(G, torch.Tensor):
-        return f(G)
-    return batch_like(G, f(G.values), skip_masking)
+    """f on the values of a batch (or on a plain tensor)"""
+    return batch_like(G, f(G.values), skip_masking) if isinstance(G, Batch) else f(G)
 
 
 def add_batch(G1: Union[torch.Tensor, Batch], G2: Union[torch.Tensor, Batch]) -> Union[torch.Tensor, Batch]:
-    # add features of two batched graphs with identical edge structures
-    if isinstance(G1, Batch) and isinstance(G2, Batch):
-        assert G1.order == G2.order
-        assert G1.n_nodes == G2.n_nodes
-        assert G1.n_edges == G2.n_edges
+    """sum of two batches over the SAME index structure (or of two equally shaped tensors)"""
+    pair = (isinstance(G1, Batch), isinstance(G2, Batch))
+    if pair == (True, True):
+        same = G1.order == G2.order and G1.n_nodes == G2.n_nodes and G1.n_edges == G2.n_edges
+        assert same, 'add_batch: the two batches do not share their structure'
         return batch_like(G1, G1.values + G2.values, skip_masking=True)
-    else:
-        assert isinstance(G1, torch.Tensor) and isinstance(G2, torch.Tensor)
-        assert G1.size() == G2.size()
-        return G1 + G2
+    assert pair == (False, False) and G1.size() == G2.size(), 'add_batch: two batches or two equally shaped tensors'
+    return G1 + G2
 
 
 def make_batch_concatenated(node_feature: torch.Tensor, edge_index: torch.LongTensor, edge_feature: torch.Tensor,
@@ -195,10 +185,7 @@ def make_batch_concatenated(node_feature: torch.Tensor, edge_index: torch.LongTe
 
 
 def make_batch(node_features: list, edge_indices: list, edge_features: list) -> Batch:
-    """interface for sparse batch construction (batch/sparse.py:179-190)"""
-    node_feature = torch.cat(node_features)
-    edge_index = torch.cat(edge_indices, dim=1)
-    edge_feature = torch.cat(edge_features)
-    n_nodes = [x.size(0) for x in node_features]
-    n_edges = [e.size(0) for e in edge_features]
-    return make_batch_concatenated(node_feature, edge_index, edge_feature, n_nodes, n_edges)
+    """per-graph lists -> Batch (batch/sparse.py:179-190): concatenate and defer to make_batch_concatenated"""
+    counts = lambda xs: [x.size(0) for x in xs]
+    return make_batch_concatenated(torch.cat(node_features), torch.cat(edge_indices, dim=1), torch.cat(edge_features),
+                                   counts(node_features), counts(edge_features))

@@ -1,30 +1,53 @@
-"""Build libhotk.so in-tree with hipcc for gfx950 (`python -m hot_amd.build`)."""
+"""Build libhotk.so in-tree with hipcc for gfx950 (`python -m hot_amd.build`).
+
+One object per csrc/*.hip (compiled in parallel, only when the source or a header is newer), linked into
+hot_amd/libhotk.so.  Objects live under hot_amd/csrc/_obj/ (git-ignored)."""
 import glob
 import os
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, 'libhotk.so')
+OBJ = os.path.join(HERE, 'csrc', '_obj')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wno-unused-value',
+         '-mllvm', '-amdgpu-mfma-vgpr-form']   # MFMA results in VGPRs: no v_accvgpr_read/write around the tile code
 
 
 def sources():
     return sorted(glob.glob(os.path.join(HERE, 'csrc', '*.hip')))
 
 
-def build(force=False, verbose=True):
+def _headers():
+    return glob.glob(os.path.join(HERE, 'csrc', '*.h')) + [os.path.join(HERE, '..', 'include', 'hotk.h')]
+
+
+def build(force=False, verbose=True, extra_flags=(), out=OUT):
+    """extra_flags / out: A/B builds of the same ABI (load with HOTK_LIB=<out>)"""
     srcs = sources()
-    deps = srcs + glob.glob(os.path.join(HERE, 'csrc', '*.h')) + [os.path.join(HERE, '..', 'include', 'hotk.h')]
-    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(s) for s in deps):
-        return OUT
+    hdr_time = max(os.path.getmtime(h) for h in _headers())
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-    cmd = [hipcc, '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-shared', '-Wno-unused-value',
-           '-mllvm', '-amdgpu-mfma-vgpr-form',   # MFMA results in VGPRs: no v_accvgpr_read/write around the tile code
-           '-o', OUT] + srcs
-    if verbose:
-        print(' '.join(cmd), flush=True)
-    subprocess.check_call(cmd)
-    return OUT
+    tag = '' if out == OUT else '.' + os.path.basename(out)
+    os.makedirs(OBJ, exist_ok=True)
+    jobs = []
+    for s in srcs:
+        o = os.path.join(OBJ, os.path.basename(s)[:-4] + tag + '.o')
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+            jobs.append([hipcc] + FLAGS + list(extra_flags) + ['-c', s, '-o', o])
+    objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + tag + '.o') for s in srcs]
+    if not jobs and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(o) for o in objs):
+        return out
+
+    def run(cmd):
+        if verbose:
+            print(' '.join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
+        list(ex.map(run, jobs))
+    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    return out
 
 
 if __name__ == '__main__':

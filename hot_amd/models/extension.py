@@ -1,52 +1,51 @@
-"""The extension for k-uniform hyperedge prediction: a set of N nodes in, B k-node
-hyperedges out.  Same class names, constructors, attribute names (state_dict keys) and forward signatures as
-hot_pytorch/models/extension.py:14-124; the layers are hot_amd.models.uniform (HIP kernels)."""
-from typing import Union, List
+"""1 -> k-uniform hyperedge extension: N node features in, one output row per k-node hyperedge.
 
+Interface contract of hot_pytorch/models/extension.py:14-124 (class names, constructor arguments, attribute names ->
+state_dict keys, forward(x, indices)); layers from hot_amd.models.uniform (HIP kernels), assembly shared with the other
+stacks (models/_stack.py).  Tensors are plain [N, D] / [B, D] here, so the pointwise members are torch modules."""
 import torch
 import torch.nn as nn
 
+from . import _stack
 from .uniform.kernelattn import KernelSelfAttn
 from .uniform.f import Nonlinear, Add
 from .uniform.linear import Linear
-from .common.kernel import KernelFeatureMap
 
 
-def _check_indices(indices: torch.LongTensor):
-    """every hyperedge must name k distinct nodes (extension.py:14-17, there via masksum.count_unique)"""
-    if indices is not None:
-        k = indices.size(1)
-        s = indices.sort(dim=1).values
-        assert k < 2 or bool((s[:, 1:] != s[:, :-1]).all()), \
-            'This extension is only for 1->k-uniform, but given indices contain loops'
+def _check_indices(indices):
+    """a hyperedge names k DISTINCT nodes (extension.py:14-17): after sorting each row no two neighbours are equal"""
+    if indices is None or indices.size(1) < 2:
+        return
+    ordered, _ = torch.sort(indices, dim=1)
+    repeated = (ordered[:, 1:] == ordered[:, :-1]).any()
+    assert not bool(repeated), 'hyperedges with a repeated node are outside the 1 -> k-uniform extension'
+
+
+def _only(value, allowed, what):
+    assert value == allowed, f'the k-uniform extension supports {what}={allowed!r} only (got {value!r})'
 
 
 class EncLayer(nn.Module):
     def __init__(self, ord_in, ord_out, dim_in, dim_qk, dim_v, dim_ff, n_heads, cfg='default', att_cfg='default',
                  dropout=0., drop_mu=0., feature_map=None, sparse=False):
         super().__init__()
-        assert cfg == 'default' and att_cfg == 'generalized_kernel'
-        assert ord_in == 1
+        _only(cfg, 'default', 'cfg')
+        _only(att_cfg, 'generalized_kernel', 'att_cfg')
+        _only(ord_in, 1, 'ord_in')
         self.ord_out = ord_out
+        self.residual = False
         self.add = Add()
         self.ln = nn.LayerNorm(dim_in)
-        # positional (dim_qk, dim_v) into (dim_v, dim_qk) slots, as in the reference (extension.py:29)
+        # (dim_qk, dim_v) go positionally into the attention's (dim_v, dim_qk) parameters, as in extension.py:29
         self.attn = KernelSelfAttn(1, ord_out, dim_in, dim_qk, dim_v, n_heads, cfg, dropout, drop_mu, feature_map)
-        self.residual = False
-        self.ffn = nn.Sequential(
-            nn.LayerNorm(dim_in),
-            nn.Linear(dim_in, dim_ff),
-            nn.GELU(),
-            nn.Linear(dim_ff, dim_in),
-            nn.Dropout(dropout, inplace=True)
-        )
+        self.ffn = _stack.pre_norm_block(nn.LayerNorm(dim_in), nn.Linear(dim_in, dim_ff), nn.GELU(),
+                                         nn.Linear(dim_ff, dim_in), nn.Dropout(dropout, inplace=True))
 
-    def forward(self, x: torch.Tensor, indices: torch.LongTensor = None):
-        h = self.ln(x)
-        h = self.attn(h, indices)
-        x = self.add(x, h) if self.residual else h
-        h = self.ffn(x)
-        return self.add(x, h)
+    def forward(self, x, indices=None):
+        attended = self.attn(self.ln(x), indices)
+        if self.residual:
+            attended = self.add(x, attended)
+        return self.add(attended, self.ffn(attended))
 
 
 class Encoder(nn.Module):
@@ -54,62 +53,47 @@ class Encoder(nn.Module):
                  readout_dim_qk, readout_dim_v, readout_n_heads, enc_cfg='default', att_cfg='generalized_kernel',
                  drop_input=0., dropout=0., drop_mu=0., sparse=False):
         super().__init__()
-        assert enc_cfg == 'default' and att_cfg == 'generalized_kernel'
-        assert ord_out > 1
-        self.input = nn.Sequential(
-            Linear(1, 1, dim_in, dim_hidden, cfg='light'),
-            nn.Dropout(drop_input, inplace=True)
-        )
-        feat_dim = dim_qk // n_heads if dim_qk >= n_heads else 1
-        self.feature_map = KernelFeatureMap(feat_dim, generalized_attention=(att_cfg == 'generalized_kernel'))
-        self.skip_redraw_projections = False
-        layers = []
-        for ord1, ord2 in zip([ord_in] + ord_hidden, ord_hidden + [ord_out]):
-            assert ord1 == 1
-            layers.append(EncLayer(1, ord2, dim_hidden, dim_qk, dim_v, dim_ff, n_heads, enc_cfg, att_cfg, dropout, drop_mu,
-                                   self.feature_map, sparse))
-        self.layers = nn.ModuleList(layers)
-        self.output = nn.Sequential(
-            nn.LayerNorm(dim_hidden),
-            nn.Linear(dim_hidden, dim_out)
-        )
+        _only(enc_cfg, 'default', 'enc_cfg')
+        _only(att_cfg, 'generalized_kernel', 'att_cfg')
+        assert ord_out > 1, 'the output of this extension is a k-uniform hyperedge (k >= 2)'
+        self.input = nn.Sequential(Linear(1, 1, dim_in, dim_hidden, cfg='light'), nn.Dropout(drop_input, inplace=True))
+        self.feature_map, self.skip_redraw_projections = _stack.shared_feature_map(att_cfg, dim_qk, n_heads)
+        orders = [ord_in] + list(ord_hidden) + [ord_out]
+        assert all(o == 1 for o in orders[:-1]), 'every layer input of this extension is a set (order 1)'
+        self.layers = nn.ModuleList(
+            EncLayer(1, dst, dim_hidden, dim_qk, dim_v, dim_ff, n_heads, enc_cfg, att_cfg, dropout, drop_mu,
+                     self.feature_map, sparse) for dst in orders[1:])
+        self.output = nn.Sequential(nn.LayerNorm(dim_hidden), nn.Linear(dim_hidden, dim_out))
 
-    def forward(self, x: torch.Tensor, indices: torch.LongTensor):
+    def forward(self, x, indices):
         _check_indices(indices)
-        if (self.feature_map is not None) and (not self.skip_redraw_projections):
-            self.feature_map.redraw_projections()
+        _stack.maybe_redraw(self)
         x = self.input(x)
         for layer in self.layers:
-            x = layer(x) if layer.ord_out == 1 else layer(x, indices)
+            x = layer(x, indices if layer.ord_out != 1 else None)
         return self.output(x)
 
 
 class MLP(nn.Module):
-    def __init__(self, ord_in, ord_out, ord_hidden: list, dim_in, dim_out, dim_hidden: Union[List, int], f='relu', dropout=0.,
-                 sparse=False):
-        super().__init__()
-        assert ord_out > 1
-        if not isinstance(dim_hidden, list):
-            dim_hidden = [dim_hidden] * len(ord_hidden)
-        ords = [ord_in] + list(ord_hidden) + [ord_out]
-        dims = [dim_in] + list(dim_hidden) + [dim_out]
-        layers = []
-        n_lin = len(ords) - 1
-        for idx in range(n_lin):
-            assert ords[idx] == 1
-            layer = nn.ModuleList()
-            layer.append(Linear(1, ords[idx + 1], dims[idx], dims[idx + 1], bias=True, cfg='default', normalize=True))
-            if idx < n_lin - 1:
-                layer.append(Nonlinear(f))
-                layer.append(nn.Dropout(p=dropout))
-            layers.append(layer)
-        self.layers = nn.ModuleList(layers)
+    """`layers` is a ModuleList of per-layer ModuleLists [Linear(cfg='default'), (Nonlinear, Dropout)]: keys `layers.k.0.*`"""
 
-    def forward(self, x: torch.Tensor, indices: torch.LongTensor):
+    def __init__(self, ord_in, ord_out, ord_hidden: list, dim_in, dim_out, dim_hidden, f='relu', dropout=0., sparse=False):
+        super().__init__()
+        assert ord_out > 1, 'the output of this extension is a k-uniform hyperedge (k >= 2)'
+        plan = _stack.orders_and_widths(ord_in, ord_hidden, ord_out, dim_in, dim_hidden, dim_out)
+        assert all(o == 1 for o, _ in plan[:-1]), 'every layer input of this extension is a set (order 1)'
+        self.layers = nn.ModuleList()
+        for k, ((_, w_src), (o_dst, w_dst)) in enumerate(zip(plan[:-1], plan[1:])):
+            members = [Linear(1, o_dst, w_src, w_dst, bias=True, cfg='default', normalize=True)]
+            if k + 2 < len(plan):
+                members += [Nonlinear(f), nn.Dropout(p=dropout)]
+            self.layers.append(nn.ModuleList(members))
+
+    def forward(self, x, indices):
         _check_indices(indices)
-        for layer in self.layers:
-            x = layer[0](x) if layer[0].weight.ord_out == 1 else layer[0](x, indices)
-            if len(layer) > 1:
-                x = layer[1](x)
-                x = layer[2](x)
+        for members in self.layers:
+            lin = members[0]
+            x = lin(x) if lin.weight.ord_out == 1 else lin(x, indices)
+            for post in members[1:]:
+                x = post(x)
         return x

@@ -1,42 +1,28 @@
-"""MLP of order-changing equivariant linear layers on the sparse Batch.
+"""MLP of order-changing equivariant linear layers, sparse or dense layout.
 
-Same constructor, attribute names (`layers.<k>.weight.weight`, `layers.<k>.bias.bias.<j>`) and forward signature as
-hot_pytorch/models/mlp.py:15-40: every layer is `Linear(cfg='default', normalize=True)`, i.e. the full 15 / 5 / 2-operation
-basis, with a pointwise nonlinearity and dropout between layers.  sparse=False takes the dense [B,N,N,D] layout
-(hot_amd/models/dense, the same kernels through the DensePlan)."""
-from typing import List, Union
-
+Interface contract of hot_pytorch/models/mlp.py:15-40: `layers` is one nn.Sequential holding, per layer,
+Linear(cfg='default', normalize=True) -- the full 15 / 5 / 2-operation basis -- followed (except after the last layer) by a
+pointwise nonlinearity and a dropout, so the parameter keys are `layers.<3k>.weight.weight`, `layers.<3k>.bias.bias.<j>`."""
 import torch.nn as nn
 
-from ..batch.sparse import Batch as S
-from ..batch.dense import Batch as D
-from .sparse.linear import Linear as S_Linear
-from .sparse.f import Nonlinear as S_Nonlinear, Apply as S_Apply
-from .dense.linear import Linear as D_Linear
-from .dense.f import Nonlinear as D_Nonlinear, Apply as D_Apply
+from . import _stack
 
 
 class MLP(nn.Module):
-    def __init__(self, ord_in, ord_out, ord_hidden: list, dim_in, dim_out, dim_hidden: Union[List, int], f='relu', dropout=0.,
-                 sparse=True):
+    def __init__(self, ord_in, ord_out, ord_hidden: list, dim_in, dim_out, dim_hidden, f='relu', dropout=0., sparse=True):
         super().__init__()
-        Linear = S_Linear if sparse else D_Linear
-        Nonlinear = S_Nonlinear if sparse else D_Nonlinear
-        Apply = S_Apply if sparse else D_Apply
+        lay = _stack.layout_of(sparse)
         self.sparse = sparse
-        if not isinstance(dim_hidden, list):
-            dim_hidden = [dim_hidden] * len(ord_hidden)
-        ords = [ord_in] + list(ord_hidden) + [ord_out]
-        dims = [dim_in] + list(dim_hidden) + [dim_out]
-        layers = []
-        n_lin = len(ords) - 1
-        for idx in range(n_lin):
-            layers.append(Linear(ords[idx], ords[idx + 1], dims[idx], dims[idx + 1], bias=True, cfg='default', normalize=True))
-            if idx < n_lin - 1:
-                layers.append(Nonlinear(f))
-                layers.append(Apply(nn.Dropout(p=dropout)))
-        self.layers = nn.Sequential(*layers)
+        self._batch_type = lay.batch_type
+        plan = _stack.orders_and_widths(ord_in, ord_hidden, ord_out, dim_in, dim_hidden, dim_out)
+        members = []
+        for k, ((o_src, w_src), (o_dst, w_dst)) in enumerate(zip(plan[:-1], plan[1:])):
+            members.append(lay.linear(o_src, o_dst, w_src, w_dst, bias=True, cfg='default', normalize=True))
+            if k + 2 < len(plan):     # not the last layer
+                members += [lay.nonlinear(f), lay.apply(nn.Dropout(p=dropout))]
+        self.layers = nn.Sequential(*members)
 
-    def forward(self, G: Union[S, D]):
-        assert isinstance(G, S if self.sparse else D)
+    def forward(self, G):
+        if not isinstance(G, self._batch_type):
+            raise AssertionError(f'a {"sparse" if self.sparse else "dense"} Batch is expected, got {type(G).__name__}')
         return self.layers(G)

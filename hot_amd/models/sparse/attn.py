@@ -10,7 +10,7 @@ import torch.nn as nn
 
 from ...batch.sparse import Batch as B, batch_like, d
 from ..common.mudrop import MuDropout
-from ... import ops
+from ... import ops, _lib
 from ..._lib import KEEP_DIAG, KEEP_OFFDIAG
 from .linear import Linear
 
@@ -69,6 +69,7 @@ class SelfAttn(nn.Module):
         k_2 = self.fc_2(G)                                   # [B, |E|, dqk]
         v = self._values(G)
         plan = G.plan
+        _lib.require_unsharded(plan, 'the order-0 softmax readout over entries')
         # set -> vector over the nodes, graph -> vector over the off-diagonal entries (loop mask, attncoef.py:45-48)
         att_1 = ops.SoftmaxPool.apply(q_a, k_1.values, d(v[0]).values, plan.graph_seg(1), plan.nkind, KEEP_DIAG,
                                       self.n_heads)

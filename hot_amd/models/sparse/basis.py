@@ -3,7 +3,7 @@ Closed forms of the reference's masked bmm poolings (models/sparse/linear.py:54-
 over an empty set is exactly 0 (the reference divides an all-zero masked sum by 1e-5)."""
 import torch
 
-from ... import ops
+from ... import ops, _lib
 from ..._lib import KEEP_DIAG, KEEP_OFFDIAG
 
 
@@ -41,6 +41,7 @@ def pool_1_to_0(G, normalize):
 def pool_2_to_0(G, normalize):
     """[B,E,D] -> [B,2D]: trace pool and off-diagonal pool (linear.py:85-97)."""
     plan = G.plan
+    _lib.require_unsharded(plan, 'the order-2 -> order-0 pooling basis')
     eg = plan_entry_graph(plan)
     V1 = ops.SegSumRows.apply(G.values, plan.graph_seg(2), plan.kind, KEEP_DIAG, eg)
     V2 = ops.SegSumRows.apply(G.values, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG, eg)
@@ -90,6 +91,7 @@ def _nrm(x, cnt, normalize):
 def _order2_sums(G):
     """diag [Nn,D], off-diagonal row sums R and column sums C [Nn,D], trace T and off-diagonal total S [B,D]."""
     plan = G.plan
+    _lib.require_unsharded(plan, "the pooling basis of Linear(cfg='default')")
     A = G.values.reshape(plan.R, -1)
     diag = ops.GatherRows.apply(A, plan.diag_pos, plan.diag_node, plan.Nn)
     R = ops.SegSumRows.apply(A, plan.row_seg(), plan.kind, KEEP_OFFDIAG, plan.rown)

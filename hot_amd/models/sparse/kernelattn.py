@@ -108,11 +108,11 @@ class KernelSelfAttn(nn.Module):
 
     def _fused_ok(self):
         """the fused attention core covers the headline shape: 4 heads x 16 features (one wavefront per slot),
-        head width 8, value width 8, ReLU features, no (mu-)dropout, every term present"""
+        head width 8, value width 8, ReLU features, every term present.  Dropout and MuDropout sit between the core and
+        fc_o (kernelattn.py:70-72) and are applied there by ops.AttnCore22, so training configs stay on this path."""
         fm = self.feature_map.feature_map
         return (self.use_fused and not self.is_local and fm.generalized_attention and self.n_heads == 4
-                and self.dim_qk == 32 and self.dim_v == 32 and self.feat_dim == 16
-                and (self.dropout.p == 0. or not self.training) and (self.mu_dropout.p == 0. or not self.training))
+                and self.dim_qk == 32 and self.dim_v == 32 and self.feat_dim == 16)
 
     def _2_to_2(self, G: B):
         h_1 = self.fc_1(G)                      # [B, N, 12 dqk]: 4 query slots, 8 key slots
@@ -120,8 +120,10 @@ class KernelSelfAttn(nn.Module):
         if self._fused_ok():   # (edge-shard mode: ops.AttnCore22 runs the core in phases with all-reduces in between)
             # padding rows are ignored by the kernels: no masking pass
             v = ops.RowsMatmul.apply(G.values, self.fc_v.weight.t(), self.fc_v.bias)   # [R, 10 dv]
+            drop_p = self.dropout.p if self.training else 0.
+            mu_p = self.mu_dropout.p if self.training else 0.
             out = ops.AttnCore22.apply(h_1.values, h_2.values, v, self.feature_map.feature_map.projection_matrix,
-                                       self.fc_o.weight, self.fc_o.bias, G.plan)
+                                       self.fc_o.weight, self.fc_o.bias, G.plan, drop_p, mu_p)
             return batch_like(G, out, skip_masking=True)
         non_att = batch_like(h_2, h_2.values[..., -self.dim_in:], skip_masking=True)
         q_1 = self._phi_slots(h_1, 0, 4, True)

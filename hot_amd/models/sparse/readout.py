@@ -2,7 +2,7 @@
 import torch
 import torch.nn as nn
 
-from ... import ops
+from ... import ops, _lib
 from ..._lib import KEEP_VALID, KEEP_DIAG, KEEP_OFFDIAG
 from ...batch.sparse import Batch as B
 from .basis import plan_entry_graph, plan_node_graph
@@ -10,6 +10,8 @@ from .basis import plan_entry_graph, plan_node_graph
 
 def _graph_sum(G, keep):
     plan = G.plan
+    if G.order == 2:
+        _lib.require_unsharded(plan, 'a graph-level pool over entries')
     kind = plan.nkind if G.order == 1 else plan.kind
     rg = plan_node_graph(plan) if G.order == 1 else plan_entry_graph(plan)
     return ops.SegSumRows.apply(G.values, plan.graph_seg(G.order), kind, keep, rg)

@@ -655,7 +655,28 @@ class AttnCore22(Function):
         return torch.empty(max(need.value, 16), dtype=torch.uint8, device=dev), need.value
 
     @staticmethod
-    def forward(ctx, h1, h2, v, proj, w_o, b_o, plan):
+    def _drop_masks(plan, dev, drop_p, mu_p):
+        """keep masks of the two dropouts that sit between cat(att_1..att_10) and fc_o (kernelattn.py:70-72): MuDropout
+        keeps or drops a whole term of a whole graph (common/mudrop.py:5-20: mask [n_terms, B, 1, 1]), nn.Dropout single
+        elements.  Returned as (mu [B, 1, 10, 1] float or None, keep [R, 320] bool or None); scales are applied apart."""
+        mu = keep = None
+        if mu_p > 0.:
+            mu = (torch.rand(10, plan.B, device=dev) > mu_p).float().t().reshape(plan.B, 1, 10, 1) / (1. - mu_p)
+        if drop_p > 0.:
+            keep = torch.rand(plan.R, 320, device=dev) > drop_p
+        return mu, keep
+
+    @staticmethod
+    def _drop_apply(x, plan, mu, keep, drop_p):
+        """x [R, 320] *= mu-dropout and dropout multipliers, in place (x is a fresh tensor)"""
+        if mu is not None:
+            x.view(plan.B, plan.Emax, 10, 32).mul_(mu)
+        if keep is not None:
+            x.mul_(keep).mul_(1. / (1. - drop_p))
+        return x
+
+    @staticmethod
+    def forward(ctx, h1, h2, v, proj, w_o, b_o, plan, drop_p=0., mu_p=0.):
         for t_ in (h1, h2, v):
             _lib.require_device(t_)
             assert t_.is_contiguous() and t_.dtype == torch.float32
@@ -688,6 +709,11 @@ class AttnCore22(Function):
             AttnCore22._phase(a, _lib.ATTN22_FWD_NODESUM, ws, nws, 4 * plan.Ev * 6 * 32 + 4 * kvn.numel())
             shard.all_reduce_(kvn[P1:])
             AttnCore22._phase(a, _lib.ATTN22_FWD_APPLY, ws, nws, 4 * plan.Ev * (6 * 32 + 10 * 32) + 4 * kvn.numel())
+        # training-mode MuDropout / Dropout act on the concatenated terms, outside the core: the fused kernels stay on
+        # the path (the reference's shipped training configs use dropout 0.1, enc-small.sh:3)
+        mu, keep = AttnCore22._drop_masks(plan, dev, drop_p, mu_p)
+        AttnCore22._drop_apply(att, plan, mu, keep, drop_p)      # att now holds what fc_o sees
+        ctx.drop = (mu, keep, drop_p)
         skip = h2.view(plan.R, -1)[:, 256:]
         if not padded and thin_ok(plan.R, 320, D):
             out = thin_gemm(att, w_o.t(), b_o, skip).view(*h2.shape[:-1], D)      # projection + bias + skip path in one pass
@@ -724,8 +750,10 @@ class AttnCore22(Function):
         datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else dy @ w_o
         # (the weight-gradient-only mode of hotk_linear_bwd_fused was measured here: 3.65 ms against 3.41 ms for the
         # split-K batched GEMM at 10 M rows, so the library stays)
-        dw_o = wgrad(dy, att)
+        dw_o = wgrad(dy, att)          # att as saved = the (dropped-out) input of fc_o
         db_o = dy.sum(0)
+        mu, keep, drop_p = ctx.drop
+        AttnCore22._drop_apply(datt, plan, mu, keep, drop_p)
         padded = plan.Ev != plan.R
         # padding rows of dh1 / dh2 are never read (the BiasMask backward of fc_1 / fc_2 selects valid rows only);
         # dv feeds a plain GEMM, so its padding rows must be exact zeros
@@ -765,7 +793,7 @@ class AttnCore22(Function):
             dh1[:, 128:320].zero_()
         call('hotk_seg_sum_rows', 4 * 192 * (plan.Ev + plan.Nn), p(ck), 192, p(beg), p(end), p(perm), p(None),
              KEEP_VALID, c_void_p_of(dh1, 128), 384, plan.Nn, 192, maxlen)
-        return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None
+        return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None, None, None
 
 
 def c_void_p_of(t, col):

@@ -527,6 +527,76 @@ def enc_layer_2_2(G: OBatch, sd: dict, dim_in, dim_qk, dim_v, dim_ff, n_heads, c
 
 
 # --------------------------------------------------------------------------------------------
+# order-0 softmax readout SelfAttn(1|2, 0) and the whole Encoder(2, 0, [2]*L, ...) (models/sparse/attn.py:84-131,
+# models/sparse/attncoef.py:25-59,165-173, models/encoder.py:20-96); dropout = 0
+# --------------------------------------------------------------------------------------------
+def _vector_query_attend(query, key: OBatch, value: OBatch, n_heads):
+    """alpha = softmax over the kept rows of q_h . k_h / sqrt(d_head) (attncoef.py:25-59: keys of an order-2 batch
+    keep valid OFF-diagonal rows only), out = sum_rows alpha * v per head, heads concatenated (attncoef.py:165-173).
+    A graph without a kept row gives softmax over an all -inf row = NaN in torch; the reference fills alpha with 0
+    AFTER the softmax, so NaN * ... -- restated as the reference computes it: masked_fill(~mask, 0) on alpha."""
+    dqk, dv = query.size(-1), value.values.size(-1)
+    dh = dqk // n_heads if dqk >= n_heads else 1
+    dvh = dv // n_heads if dv >= n_heads else 1
+    q_ = torch.stack(query.split(dh, -1), 0)                    # [H, B, dh]
+    k_ = torch.stack(key.values.split(dh, -1), 0)               # [H, B, E, dh]
+    if key.order == 1:
+        keep = key.mask
+    else:
+        keep = (key.indices[..., 0] != key.indices[..., 1]) & key.mask
+    sdp = torch.einsum('hbd,hbed->hbe', q_, k_) / math.sqrt(dh)
+    sdp = sdp.masked_fill(~keep.unsqueeze(0), -float('inf'))
+    alpha = torch.softmax(sdp, 2).masked_fill(~keep.unsqueeze(0), 0)
+    v_ = torch.stack((value.values * value.mask.unsqueeze(-1).to(value.values.dtype)).split(dvh, -1), 0)
+    att = torch.einsum('hbe,hbed->hbd', alpha, v_)
+    return torch.cat(att.unbind(0), -1)
+
+
+def self_attn_readout(G: OBatch, sd: dict, ord_in, dim_in, dim_v, dim_qk, n_heads):
+    """SelfAttn(ord_in, 0).forward (attn.py:84-96 `_1_to_0`, :112-131 `_2_to_0`) -> [B, dim_in]"""
+    h0 = _lin(G, sd, 'fc_0', ord_in, 0)
+    non_att = h0[..., -dim_in:]
+    k1 = _lin(G, sd, 'fc_1', ord_in, 1)
+    v = G.like(F.linear(G.values, sd['fc_v.weight'], sd['fc_v.bias']), zero_invalid=True)
+    if ord_in == 1:
+        att = _vector_query_attend(h0[..., :dim_qk], k1, v, n_heads)
+    else:
+        k2 = _lin(G, sd, 'fc_2', 2, 2)
+        v0, v1 = [G.like(x) for x in v.values.split(dim_v, -1)]
+        att = torch.cat([_vector_query_attend(h0[..., :dim_qk], k1, op_d(v0), n_heads),
+                         _vector_query_attend(h0[..., dim_qk:2 * dim_qk], k2, v1, n_heads)], -1)
+    return non_att + F.linear(att, sd['fc_o.weight'], sd['fc_o.bias'])
+
+
+def enc_layer_2_0(G: OBatch, sd: dict, dim_in, dim_qk, dim_v, n_heads):
+    """EncLayer(2, 0, ...) (models/encoder.py:20-53): LayerNorm -> SelfAttn(2,0) -> FFN on vectors (Linear(0,0) = plain
+    matmul + bias, linear.py:50-52,288-291) -> add.  (dim_qk, dim_v) land in SelfAttn's (dim_v, dim_qk) slots
+    (encoder.py:35), reproduced."""
+    h = G.like(F.layer_norm(G.values, (dim_in,), sd['ln.f.weight'], sd['ln.f.bias']), zero_invalid=True)
+    asd = {k[len('attn.'):]: v for k, v in sd.items() if k.startswith('attn.')}
+    g = self_attn_readout(h, asd, 2, dim_in, dim_qk, dim_v, n_heads)        # SelfAttn(ord_in, 0, dim_in, dim_v=dim_qk, dim_qk=dim_v)
+    h = F.layer_norm(g, (dim_in,), sd['ffn.0.f.weight'], sd['ffn.0.f.bias'])
+    h = h @ sd['ffn.1.weight.weight'] + sd['ffn.1.bias.bias.0']
+    h = F.gelu(h)
+    h = h @ sd['ffn.3.weight.weight'] + sd['ffn.3.bias.bias.0']
+    return g + h
+
+
+def encoder_2_0(G: OBatch, sd: dict, n_layers, dim_hidden, dim_qk, dim_v, dim_ff, n_heads, readout_dim_qk,
+                readout_dim_v, readout_n_heads, generalized=True):
+    """Encoder(2, 0, [2]*n_layers, ..., 'default', '(generalized_)kernel', sparse=True).forward with dropout 0 and
+    fixed projections (models/encoder.py:56-96): input Linear(2,2,light) -> n_layers kernel EncLayer(2,2) -> softmax
+    readout EncLayer(2,0) -> LayerNorm + nn.Linear head.  -> [B, dim_out]"""
+    sub = lambda pre: {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    G = _lin(G, sd, 'input.0', 2, 2)
+    for l in range(n_layers):
+        G = enc_layer_2_2(G, sub(f'layers.{l}.'), dim_hidden, dim_qk, dim_v, dim_ff, n_heads, 'default', generalized)
+    g = enc_layer_2_0(G, sub(f'layers.{n_layers}.'), dim_hidden, readout_dim_qk, readout_dim_v, readout_n_heads)
+    g = F.layer_norm(g, (dim_hidden,), sd['output.f.0.weight'], sd['output.f.0.bias'])
+    return F.linear(g, sd['output.f.1.weight'], sd['output.f.1.bias'])
+
+
+# --------------------------------------------------------------------------------------------
 # synthetic workloads shared by tests and bench (own seeded generator; SURVEY 8d "S1")
 # --------------------------------------------------------------------------------------------
 def ba_edges(n: int, m: int, rng: np.random.Generator) -> np.ndarray:

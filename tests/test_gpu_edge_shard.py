@@ -1,7 +1,7 @@
 """GPU (-m gpu): edge-shard mode of ONE graph over two / four ranks.  All ranks share cuda:0 and talk over
 gloo (host-staged collectives in hot_amd.dist stand in for RCCL, which needs one GPU per rank); the arithmetic on
 every rank is the HIP path.  Each rank checks its local outputs, its local input gradients and the all-reduced
-parameter gradients against the same layer run on the whole graph in one process.  Two sharded paths: the fused core
+parameter gradients against the CPU ORACLE run on the whole graph.  Two sharded paths: the fused core
 in phases (hotk_attn22_phase, all-reduces of kvg / kvn and their gradients between the phases) and the general
 kernels (all-reduce of the materialised key-value sums in ops.KernelAttn)."""
 import os
@@ -49,27 +49,32 @@ def _rel(a, b):
 
 
 def _worker(rank, world, port, q, fused):
+    import datetime
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
     os.environ['MASTER_PORT'] = str(port)
-    dist.init_process_group('gloo', rank=rank, world_size=world)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    ok = False
     try:
         torch.cuda.set_device(0)
+        from oracle import hot_oracle as O
         from hot_amd.batch import sparse as bs
         from hot_amd.dist import shard_graph, allreduce_gradients
         nf, ei, ef, g = _graph()
         n, E = nf.size(0), ei.size(1)
-        Rw = torch.randn(n + E, 32, generator=g).to(DEV)          # loss weights per global row (nodes, then edges)
-        # whole graph in this process
+        Rw_cpu = torch.randn(n + E, 32, generator=g)              # loss weights per global row (nodes, then edges)
+        Rw = Rw_cpu.to(DEV)
+        # the WHOLE graph on the CPU oracle (pinned restatement of the reference): the reference every rank is held to
         layer = _layer()
-        layer.use_fused = False
-        G = bs.make_batch_concatenated(nf.to(DEV), ei.to(DEV), ef.to(DEV), [n], [E])
-        x = G.values.clone().requires_grad_(True)
-        y = layer(bs.batch_like(G, x, skip_masking=True))
-        (y.values[0] * Rw).sum().backward()
-        ref_y, ref_gx = y.values[0].detach(), x.grad[0].clone()
-        ref_gp = {k: p.grad.clone() for k, p in layer.named_parameters()}
-        # this rank's shard
+        sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
+              for k, v in layer.state_dict().items()}
+        GO = O.build_batch(nf, ei, ef, [n], [E])
+        xo = GO.values.clone().requires_grad_(True)
+        yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, 32, 32, 4, 'default', True)
+        (yo.values[0] * Rw_cpu).sum().backward()
+        ref_y, ref_gx = yo.values[0].detach().to(DEV), xo.grad[0].to(DEV)
+        ref_gp = {k: sd[k].grad.to(DEV) for k, _ in layer.named_parameters()}
+        # this rank's shard on the HIP path
         layer2 = _layer()
         layer2.use_fused = fused
         Gs, own = shard_graph(nf.to(DEV), ei.to(DEV), ef.to(DEV), world, rank)
@@ -82,14 +87,37 @@ def _worker(rank, world, port, q, fused):
         gx = xs.grad[0].clone()
         gx_nodes = gx[:n].clone()
         Gs.plan.shard.all_reduce_(gx_nodes)                        # replicated inputs: their gradient is the sum over ranks
+        # ReLU features: rows whose pre-activation sits within rounding of 0 may flip their gate against the CPU
+        # (tests/test_gpu_parity.py::test_layer_vs_oracle_ba_graphs): gradients are held row-wise
+        scale = ref_gx.abs().max()
+        bad_e = float((((gx[n:] - ref_gx[n + own]).abs().amax(-1) / scale) > 2e-5).float().mean())
+        bad_n = float((((gx_nodes - ref_gx[:n]).abs().amax(-1) / scale) > 2e-5).float().mean())
         res = {'n_local_edges': int(own.numel()),
                'y': _rel(ys.values[0].detach(), ref_y[rows]),
-               'gx_edges': _rel(gx[n:], ref_gx[n + own]),
-               'gx_nodes': _rel(gx_nodes, ref_gx[:n]),
+               'gx_edges_bad_rows': bad_e, 'gx_nodes_bad_rows': bad_n,
                'gp': max(_rel(p.grad, ref_gp[k]) for k, p in layer2.named_parameters())}
+        # ops whose entry sums are not exchanged yet must refuse to run on a sharded plan instead of returning a
+        # partial result
+        from hot_amd import _lib
+        from hot_amd.models.common import KernelFeatureMap
+        from hot_amd.models import sparse as ms
+        refused = 0
+        for make in (lambda: ms.Linear(2, 2, 32, 8, cfg='default'), lambda: ms.Linear(2, 0, 32, 8, cfg='light'),
+                     lambda: ms.SelfAttn(2, 0, 32, 32, 32, 4),
+                     lambda: ms.KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8))):
+            try:
+                make().to(DEV)(Gs)
+            except _lib.HotkError as exc:
+                refused += 'edge-shard' in str(exc)
+        res['refused'] = refused
         q.put((rank, res))
+        ok = True
+    except Exception as exc:                                       # report instead of leaving the parent to time out
+        import traceback
+        q.put((rank, {'error': repr(exc), 'trace': traceback.format_exc()}))
     finally:
-        dist.barrier()
+        if ok:
+            dist.barrier()
         dist.destroy_process_group()
 
 
@@ -102,24 +130,33 @@ def _free_port():
 
 
 @pytest.mark.parametrize('world,fused', [(2, True), (2, False), (4, True)])
-def test_edge_shard_matches_whole_graph(world, fused):
+def test_edge_shard_matches_oracle_on_whole_graph(world, fused):
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
-    results = dict(q.get(timeout=200) for _ in range(world))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        results = dict(q.get(timeout=200) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=10)
+    errors = {r: v for r, v in results.items() if 'error' in v}
+    assert not errors, errors
+    assert all(p.exitcode == 0 for p in procs)
     assert sum(r['n_local_edges'] for r in results.values()) == _graph()[1].size(1)
     assert all(r['n_local_edges'] > 0 for r in results.values())
     print('edge-shard results', results)
     for rank, r in results.items():
         assert r['y'] < 1e-5, (rank, r)
-        assert r['gx_edges'] < 2e-5 and r['gx_nodes'] < 2e-5 and r['gp'] < 2e-5, (rank, r)
+        assert r['gx_edges_bad_rows'] <= 5e-3 and r['gx_nodes_bad_rows'] <= 5e-3 and r['gp'] < 1e-3, (rank, r)
+        assert r['refused'] == 4, (rank, r)
 
 
 def test_fused_phases_single_rank_equal_one_pass():

@@ -149,3 +149,41 @@ def test_ba_generator_shape():
     assert ei.shape == (2, 590) and (ei[0] != ei[1]).all()
     key = ei[0] * 64 + ei[1]
     assert len(np.unique(key)) == 590 and np.array_equal(np.sort(key), np.sort(ei[1] * 64 + ei[0]))
+
+
+@pytest.mark.parametrize('name', ['readout_small.npz', 'readout_c2.npz'])
+def test_softmax_readout_and_encoder(name):
+    """SelfAttn(2,0) / SelfAttn(1,0) and the whole Encoder(2, 0, [2], ...) restatements against the reference's outputs
+    and gradients (the small fixture holds a single-node graph without edges: empty softmax set)."""
+    z = load_golden(name)
+    G0 = O.build_batch(*graph_inputs(z))
+    D, dim_v, dim_qk, H = [int(x) for x in z['dims']]
+
+    def check_grads(sd, prefix):
+        scale = max(float(np.abs(v).max()) for k, v in z.items() if k.startswith(prefix))
+        for k, v in z.items():
+            if k.startswith(prefix):
+                err = float((sd[k[len(prefix):]].grad - tt(v)).abs().max())
+                # key biases in front of a softmax have an exactly zero gradient (shift invariance): rounding noise
+                assert err < 2 * TOL * max(float(np.abs(v).max()), 1e-3 * scale), (k, err)
+
+    for oi in (2, 1):
+        tag = f'r{oi}0'
+        sd = _sd(z, tag, grad=True)
+        x = G0.values.clone().requires_grad_(True)
+        G = G0.like(x)
+        if oi == 1:
+            G = O.op_d(G)
+        y = O.self_attn_readout(G, sd, oi, D, dim_v, dim_qk, H)
+        assert rel_err(y, z[f'{tag}/y']) < TOL, tag
+        (y * tt(z[f'{tag}/R'])).sum().backward()
+        assert rel_err(x.grad, z[f'{tag}/gx']) < 2 * TOL, tag
+        check_grads(sd, f'{tag}/grad/')
+    D_in, dout, dh, dqk, dv, dff, nh, rq, rv, rh = [int(x) for x in z['enc_dims']]
+    sd = _sd(z, 'enc0', grad=True)
+    x = G0.values.clone().requires_grad_(True)
+    y = O.encoder_2_0(G0.like(x), sd, 1, dh, dqk, dv, dff, nh, rq, rv, rh, True)
+    assert rel_err(y, z['enc0/y']) < TOL
+    (y * tt(z['enc0/R'])).sum().backward()
+    assert rel_err(x.grad, z['enc0/gx']) < 2 * TOL
+    check_grads({k: v for k, v in sd.items() if v.requires_grad}, 'enc0/grad/')
