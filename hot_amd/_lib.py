@@ -79,6 +79,7 @@ _SIGNATURES.update({
     'hotk_attn22_forward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
     'hotk_attn22_backward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
     'hotk_attn22_phase': [ctypes.POINTER(Attn22Args), c_int, _P, _S, _P],
+    'hotk_attn22_forward_static': [ctypes.POINTER(Attn22Args), _P],
 })
 EXPORTS = sorted(list(_SIGNATURES) + ['hotk_strerror', 'hotk_version'])
 

@@ -20,6 +20,7 @@
 // The same rotated form of the projection matrix turns  d(raw q)[j] = sum_mm dpre[mm] P[mm][j]  into 16 DPP FMAs.
 #include "common.h"
 #include <cstdlib>
+#include <mutex>
 
 namespace {
 
@@ -1477,18 +1478,12 @@ extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* byte
   return HOTK_OK;
 }
 
-extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, size_t ws_bytes, void* stream) {
-  int rc = check_args(a);
-  if (rc) return rc;
-  HOTK_CHECK_ARG(a->att && a->kvg && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
-  if (a->R == 0 || a->Nn == 0) return HOTK_OK;
-  hipStream_t st = (hipStream_t)stream;
+namespace {
+// forward launches; `part` holds the per-chunk partial graph sums (hotk_attn22_workspace_bytes): every chunk of it is
+// written by k_graphsum_fwd before k_graph_reduce reads it, so it needs no clearing
+int attn22_forward_launch(const A* a, float* part, hipStream_t st) {
   int cpg, rows;
   chunking(a->B, a->Emax, &cpg, &rows);
-  size_t need;
-  hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
-  if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-  float* part = (float*)workspace;
   unsigned g1 = hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP);
   hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
   launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
@@ -1506,6 +1501,58 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
     hipLaunchKernelGGL((k_seg_fwd<0, false>), gseg, dim3(TPB), 0, st, *a);
   }
   return hotk_launch_status();
+}
+}  // namespace
+
+extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, size_t ws_bytes, void* stream) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(a->att && a->kvg && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
+  if (a->R == 0 || a->Nn == 0) return HOTK_OK;
+  size_t need;
+  hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
+  if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
+  return attn22_forward_launch(a, (float*)workspace, (hipStream_t)stream);
+}
+
+// ---- the forward core for callers that cannot allocate (include/hotk.h: hotk_attn22_forward_static) ----------
+// The per-chunk partial graph sums live in a file-scope device array instead of a caller workspace.  Every GPU the
+// library runs on holds its own copy of the array at its own address: the address is looked up once per device with
+// hipGetSymbolAddress (the array's NAME is only a host-side stand-in and must never reach a kernel argument) and the
+// kernels take the looked-up pointer exactly as they take the workspace of hotk_attn22_forward.
+namespace {
+constexpr size_t STATIC_SCRATCH_BYTES = HOTK_ATTN22_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+constexpr int MAX_DEVICES = 64;
+std::mutex scratch_mu;
+void* scratch_ptr[MAX_DEVICES];   // per device, filled on the first call with that device current
+
+int static_scratch(float** out) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return HOTK_ELAUNCH;
+  std::lock_guard<std::mutex> lock(scratch_mu);
+  if (!scratch_ptr[dev]) {
+    void* ptr = nullptr;
+    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return HOTK_ELAUNCH;
+    scratch_ptr[dev] = ptr;
+  }
+  *out = (float*)scratch_ptr[dev];
+  return HOTK_OK;
+}
+}  // namespace
+
+extern "C" int hotk_attn22_forward_static(const hotk_attn22_args* a, void* stream) {
+  int rc = check_args(a);
+  if (rc) return rc;
+  HOTK_CHECK_ARG(a->att && a->kvg && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
+  size_t need;
+  hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
+  if (need > STATIC_SCRATCH_BYTES) return HOTK_ETOOLARGE;
+  if (a->R == 0 || a->Nn == 0) return HOTK_OK;
+  float* part = nullptr;
+  rc = static_scratch(&part);
+  if (rc) return rc;
+  return attn22_forward_launch(a, part, (hipStream_t)stream);
 }
 
 extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, size_t ws_bytes, void* stream) {

@@ -356,6 +356,7 @@ extern "C" const char* hotk_strerror(int code) {
     case HOTK_EWORKSPACE: return "workspace too small";
     case HOTK_ELAUNCH: return "HIP launch/runtime error";
     case HOTK_EUNSUPPORTED: return "unsupported configuration";
+    case HOTK_ETOOLARGE: return "problem exceeds the fixed scratch capacity of this *_static entry point (use the workspace form)";
     default: return "unknown error";
   }
 }

@@ -29,6 +29,7 @@ extern "C" {
 #define HOTK_EWORKSPACE (-2) /* workspace too small                        */
 #define HOTK_ELAUNCH (-3)  /* hipLaunch / runtime error                    */
 #define HOTK_EUNSUPPORTED (-4)
+#define HOTK_ETOOLARGE (-5) /* problem exceeds the fixed capacity of a *_static entry point */
 
 #define HOTK_KEEP_PAD 1u
 #define HOTK_KEEP_DIAG 2u
@@ -273,6 +274,18 @@ typedef struct hotk_attn22_args {
 int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes);
 int hotk_attn22_forward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
 int hotk_attn22_backward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
+
+/* hotk_attn22_forward for callers that cannot allocate device memory.  NO COUNTERPART IN THE REFERENCE (which allocates
+ * freely through PyTorch): it exists for callers under HIP graph capture, tight serving loops and harnesses that forbid
+ * hipMalloc.  Same inputs, outputs and results (bit for bit) as hotk_attn22_forward, but the per-chunk partial graph
+ * sums live in a file-scope device array of HOTK_ATTN22_STATIC_SCRATCH_BYTES inside the library (one copy per GPU the
+ * library runs on, held until the process ends) instead of a caller workspace; the call allocates and frees nothing.
+ * Limit: hotk_attn22_workspace_bytes(B, Emax) <= HOTK_ATTN22_STATIC_SCRATCH_BYTES, i.e. at most 3 640 row chunks
+ * (C2-sized minibatches: 128 molecules need 0.6-4.7 MB); larger batches return HOTK_ETOOLARGE and launch nothing.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on
+ * one stream are ordered and need no clearing in between (each call rewrites every partial it reads). */
+#define HOTK_ATTN22_STATIC_SCRATCH_BYTES (32u << 20)
+int hotk_attn22_forward_static(const hotk_attn22_args* args, void* stream);
 
 /* The same core in phases, for ONE graph whose entries are sharded over ranks (SURVEY 8e edge-shard; the reference has
  * no multi-device form of kernelattncoef.py:103-175, the sums are what its coalesce() builds on one device).  Sums over
