@@ -33,6 +33,7 @@ BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEAD
 # passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
 # profiles/r01_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at 2 M entries (per-entry figures are size-independent)
 PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4903, 'hotk_attn22_backward': 8584}
+PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_traffic_attn22.txt'
 
 
 def build_structure(n_graphs, distinct=512, seed=1234):
@@ -89,7 +90,7 @@ def cpu_baseline(n_graphs=192, threads=None):
         y.values.sum().backward()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
-    return {'value': n_entries / best, 'unit': 'entries/s', 'cores': threads, 'kind': 'port',
+    return {'value': n_entries / best, 'unit': 'entries/s', 'cores': threads, 'host_cpu_count': os.cpu_count(), 'kind': 'port',
             'sample': f'{n_graphs} BA(64,5) graphs = {n_entries} entries, fwd+bwd of the same layer, best of 3, '
                       f'oracle/hot_oracle.py on torch-CPU fp32'}
 
@@ -194,7 +195,9 @@ def main():
             traffic = PMC_TRAFFIC_BYTES_PER_ENTRY.get(prof_name)
             roof = {'bound': 'hbm', 'kernel': prof_name, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': ach * 1e9 / HBM_PEAK, 'traffic': None if traffic is None else traffic * n_entries,
-                    'traffic_source': 'profiles/r01_pmc_traffic_attn22.txt (bytes per launch = measured B/entry x entries)',
+                    'traffic_source': 'NOT measured in this run: a constant from separate rocprofv3 --pmc passes at 2 M '
+                                      'entries (PMC_TRAFFIC_SOURCE), B/entry x entries of this launch',
+                    'traffic_profile': PMC_TRAFFIC_SOURCE,
                     'launches': calls,
                     'avg_launch_ms': tot_ms / max(calls, 1),
                     'note': 'achieved = algorithmic bytes (operands read once + results written once) of the '

@@ -67,13 +67,10 @@ __global__ __launch_bounds__(AT_THREADS) void k_seg_outer_sum(
       }
     }
     float* o = KV + ((int64_t)s * F + f) * c1;
-    const bool whole = (e - b) <= HOTK_SEG_CHUNK;
 #pragma unroll
     for (int k = 0; k < AT_CT; ++k) {
       int chn = c0 + k;
-      if (chn <= c) {
-        if (whole) o[chn] = acc[k]; else atomicAdd(o + chn, acc[k]);
-      }
+      if (chn <= c) o[chn] = acc[k];
     }
   }
 }
@@ -262,8 +259,10 @@ extern "C" int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* k
   if (n_seg == 0) return HOTK_OK;
   HOTK_CHECK_ARG(K && V && KV && seg_begin && seg_end && ld_k >= (int64_t)HH * m && ld_v >= (int64_t)HH * c);
   HOTK_CHECK_ARG(!aug || ld_aug >= HH);
-  int64_t n_chunk = (max_seg_len + HOTK_SEG_CHUNK - 1) / HOTK_SEG_CHUNK;
-  if (n_chunk < 1) n_chunk = 1;
+  // one thread walks a whole segment in order; longer segments are split by the caller (hot_amd.ops.refine_seg) and the
+  // partial sums added by hotk_seg_sum_rows: no float atomics, bitwise reproducible
+  if (max_seg_len > HOTK_SEG_CHUNK) return HOTK_EUNSUPPORTED;
+  const int64_t n_chunk = 1;
   int n_tile = (c + 1 + AT_CT - 1) / AT_CT;
   int Fp = (HH * m + 63) & ~63;
   int64_t work = n_seg * n_chunk * n_tile * Fp;

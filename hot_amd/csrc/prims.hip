@@ -101,14 +101,7 @@ __global__ void k_seg_sum_rows(const float* __restrict__ src, int64_t ld_src, co
       for (int u = 0; u < SU; ++u)
         if (ok[u]) acc = vadd(acc, v[u]);
     }
-    float* o = out + s * ld_out + cv * V;
-    if (e - b <= HOTK_SEG_CHUNK) {
-      *reinterpret_cast<T*>(o) = acc;
-    } else {
-      const float* a = reinterpret_cast<const float*>(&acc);
-#pragma unroll
-      for (int k = 0; k < V; ++k) atomicAdd(o + k, a[k]);
-    }
+    *reinterpret_cast<T*>(out + s * ld_out + cv * V) = acc;
   }
 }
 
@@ -133,13 +126,15 @@ __global__ void k_bias_mask_rows(float* __restrict__ y, int64_t ld, const uint8_
   }
 }
 
-// db[k][c] += sum over rows of kind k+... : block handles a strip of rows for all channels
+// bias gradients: column sums of dy over the rows of each kind, in two passes without atomics (bitwise reproducible):
+// pass 1 leaves one partial row pair per block (part[block][0 = off-diagonal | 1 = diagonal][C]), pass 2 adds the
+// partials of a channel in block order.
 __global__ __launch_bounds__(256) void k_bias_grad_rows(const float* __restrict__ dy, int64_t ld,
-                                                        const uint8_t* __restrict__ kind, float* __restrict__ db_off,
-                                                        float* __restrict__ db_diag, int64_t n, int64_t C,
-                                                        int64_t rows_per_block) {
+                                                        const uint8_t* __restrict__ kind, float* __restrict__ part,
+                                                        int64_t n, int64_t C, int64_t rows_per_block) {
   int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block;
   if (r1 > n) r1 = n;
+  float* o = part + (int64_t)blockIdx.x * 2 * C;
   for (int64_t c = threadIdx.x; c < C; c += blockDim.x) {
     float a_off = 0.f, a_diag = 0.f;
     for (int64_t r = r0; r < r1; ++r) {
@@ -148,17 +143,16 @@ __global__ __launch_bounds__(256) void k_bias_grad_rows(const float* __restrict_
       float v = dy[r * ld + c];
       if (kd == 2) a_off += v; else a_diag += v;
     }
-    if (db_off) atomicAdd(db_off + c, a_off);
-    if (db_diag) atomicAdd(db_diag + c, a_diag);
+    o[c] = a_off;
+    o[C + c] = a_diag;
   }
 }
 
 // float4 variant: thread = (channel vector cv, row lane ty); TY rows are read in parallel, each row as whole
-// contiguous pieces; the TY partial sums meet in LDS and leave as one atomic per channel and block
+// contiguous pieces; the TY partial sums meet in LDS (added in lane order) and leave as the block's partial row pair
 __global__ __launch_bounds__(256) void k_bias_grad_rows4(const float* __restrict__ dy, int64_t ld,
-                                                         const uint8_t* __restrict__ kind, float* __restrict__ db_off,
-                                                         float* __restrict__ db_diag, int64_t n, int C4, int TY,
-                                                         int64_t rows_per_block) {
+                                                         const uint8_t* __restrict__ kind, float* __restrict__ part,
+                                                         int64_t n, int C4, int TY, int64_t rows_per_block) {
   __shared__ float4 red[2][256];
   const int cv = threadIdx.x % C4, ty = threadIdx.x / C4;
   float4 a_off = make_float4(0.f, 0.f, 0.f, 0.f), a_diag = a_off;
@@ -192,15 +186,30 @@ __global__ __launch_bounds__(256) void k_bias_grad_rows4(const float* __restrict
       a_off = vadd(a_off, red[0][k * C4 + cv]);
       a_diag = vadd(a_diag, red[1][k * C4 + cv]);
     }
-    if (db_off) {
-      atomicAdd(db_off + 4 * cv + 0, a_off.x); atomicAdd(db_off + 4 * cv + 1, a_off.y);
-      atomicAdd(db_off + 4 * cv + 2, a_off.z); atomicAdd(db_off + 4 * cv + 3, a_off.w);
-    }
-    if (db_diag) {
-      atomicAdd(db_diag + 4 * cv + 0, a_diag.x); atomicAdd(db_diag + 4 * cv + 1, a_diag.y);
-      atomicAdd(db_diag + 4 * cv + 2, a_diag.z); atomicAdd(db_diag + 4 * cv + 3, a_diag.w);
-    }
+    float* o = part + (int64_t)blockIdx.x * 2 * 4 * C4;
+    *reinterpret_cast<float4*>(o + 4 * cv) = a_off;
+    *reinterpret_cast<float4*>(o + 4 * C4 + 4 * cv) = a_diag;
   }
+}
+
+// pass 2: thread per (kind, channel); the partials are added in block order, eight loads in flight
+__global__ __launch_bounds__(256) void k_bias_grad_combine(const float* __restrict__ part, int64_t nb, int64_t C,
+                                                           float* __restrict__ db_off, float* __restrict__ db_diag) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 2 * C) return;
+  float* dst = t < C ? db_off : db_diag;
+  if (!dst) return;
+  float acc = 0.f;
+  int64_t k = 0;
+  for (; k + 8 <= nb; k += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(k + u) * 2 * C + t];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += v[u];
+  }
+  for (; k < nb; ++k) acc += part[k * 2 * C + t];
+  dst[t < C ? t : t - C] = acc;
 }
 
 // ------------------------------------------------------------------ order-2 'light' basis
@@ -402,8 +411,10 @@ extern "C" int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t
   if (n_seg == 0 || C == 0) return HOTK_OK;
   HOTK_CHECK_ARG(src && out && seg_begin && seg_end);
   hipStream_t st = (hipStream_t)stream;
-  int64_t n_chunk = (max_seg_len + HOTK_SEG_CHUNK - 1) / HOTK_SEG_CHUNK;
-  if (n_chunk < 1) n_chunk = 1;
+  // one thread walks a whole segment in order (bitwise reproducible); longer segments are split by the caller into
+  // consecutive pieces whose partial rows are summed by a second call (hot_amd.ops.refine_seg), never with atomics
+  if (max_seg_len > HOTK_SEG_CHUNK) return HOTK_EUNSUPPORTED;
+  const int64_t n_chunk = 1;
   if (vec4_ok(C, {ld_src, ld_out}, {src, out})) {
     hipLaunchKernelGGL(k_seg_sum_rows<4>, dim3(hotk_grid(n_seg * n_chunk * (C / 4), 256)), dim3(256), 0, st, src,
                        ld_src, seg_begin, seg_end, perm, kind, keep, out, ld_out, n_seg, C / 4, n_chunk);
@@ -430,26 +441,53 @@ extern "C" int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, co
   return hotk_launch_status();
 }
 
+namespace {
+// pass-1 geometry of the bias-gradient sums (shared by the workspace query and the launch)
+struct BiasGradGeom { bool vec4; int C4, TY; int64_t nb, rpb; };
+BiasGradGeom bias_grad_geom(const float* dy, int64_t ld, int64_t n, int64_t C) {
+  BiasGradGeom g{};
+  g.vec4 = C % 4 == 0 && C / 4 <= 256 && ld % 4 == 0 && hotk_aligned16(dy);
+  if (g.vec4) {
+    g.C4 = (int)(C / 4);
+    g.TY = 256 / g.C4;
+    g.nb = hotk_grid(n, 16 * g.TY, 4096);   // >= 16 rows per thread unless that needs more than 4096 blocks
+  } else {
+    g.nb = hotk_grid(n, 64, 2048);          // >= 64 rows per block
+  }
+  g.rpb = (n + g.nb - 1) / g.nb;
+  g.nb = (n + g.rpb - 1) / g.rpb;
+  return g;
+}
+}  // namespace
+
+extern "C" int hotk_bias_grad_workspace_bytes(int64_t n, int64_t C, size_t* bytes) {
+  HOTK_CHECK_ARG(bytes && n >= 0 && C >= 0);
+  // an upper bound over both geometries: at most 4096 blocks, each leaving 2 x C floats
+  int64_t nb = n < 4096 ? (n > 0 ? n : 1) : 4096;
+  *bytes = (size_t)nb * 2 * (size_t)C * sizeof(float);
+  return HOTK_OK;
+}
+
 extern "C" int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* kind, float* db_off, float* db_diag,
-                                   int64_t n, int64_t C, void* stream) {
+                                   int64_t n, int64_t C, void* workspace, size_t ws_bytes, void* stream) {
   HOTK_CHECK_ARG(n >= 0 && C >= 0 && ld >= C);
-  if (n == 0 || C == 0) return HOTK_OK;
-  HOTK_CHECK_ARG(dy && kind);
+  if (C == 0 || (!db_off && !db_diag)) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
-  if (C % 4 == 0 && C / 4 <= 256 && ld % 4 == 0 && hotk_aligned16(dy)) {
-    const int C4 = (int)(C / 4), TY = 256 / C4;
-    int64_t nb = hotk_grid(n, 16 * TY, 4096);   // >= 16 rows per thread unless that needs more than 4096 blocks
-    int64_t rpb = (n + nb - 1) / nb;
-    nb = (n + rpb - 1) / rpb;
-    hipLaunchKernelGGL(k_bias_grad_rows4, dim3((unsigned)nb), dim3(256), 0, st, dy, ld, kind, db_off, db_diag, n, C4, TY,
-                       rpb);
+  if (n == 0) {
+    hipLaunchKernelGGL(k_bias_grad_combine, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, (const float*)nullptr,
+                       (int64_t)0, C, db_off, db_diag);
     return hotk_launch_status();
   }
-  int64_t blocks = hotk_grid(n, 64, 2048);  // >= 64 rows per block
-  int64_t rpb = (n + blocks - 1) / blocks;
-  blocks = (n + rpb - 1) / rpb;
-  hipLaunchKernelGGL(k_bias_grad_rows, dim3((unsigned)blocks), dim3(256), 0, st, dy, ld, kind, db_off, db_diag, n, C,
-                     rpb);
+  HOTK_CHECK_ARG(dy && kind);
+  const BiasGradGeom g = bias_grad_geom(dy, ld, n, C);
+  if (!workspace || ws_bytes < (size_t)g.nb * 2 * (size_t)C * sizeof(float)) return HOTK_EWORKSPACE;
+  float* part = (float*)workspace;
+  if (g.vec4)
+    hipLaunchKernelGGL(k_bias_grad_rows4, dim3((unsigned)g.nb), dim3(256), 0, st, dy, ld, kind, part, n, g.C4, g.TY, g.rpb);
+  else
+    hipLaunchKernelGGL(k_bias_grad_rows, dim3((unsigned)g.nb), dim3(256), 0, st, dy, ld, kind, part, n, C, g.rpb);
+  hipLaunchKernelGGL(k_bias_grad_combine, dim3((unsigned)((2 * C + 255) / 256)), dim3(256), 0, st, part, g.nb, C, db_off,
+                     db_diag);
   return hotk_launch_status();
 }
 

@@ -76,11 +76,15 @@ def plan_of(x: torch.Tensor, indices) -> UniformPlan:
     N = x.size(0)
     if indices is None:
         return UniformPlan(N, None, x.device)
+    # the plan holds copies of the index columns and their sorted CSR: it is valid only for the tensor CONTENT it was
+    # built from, so the cache is keyed on the tensor's version counter and storage as well (an in-place refill of the
+    # same buffer for the next minibatch rebuilds it)
+    stamp = (indices._version, indices.data_ptr(), tuple(indices.shape))
     cached = getattr(indices, '_hotk_uniform_plan', None)
-    if cached is None or cached.N != N or cached.device != x.device:
-        cached = UniformPlan(N, indices, x.device)
+    if cached is None or cached[0] != stamp or cached[1].N != N or cached[1].device != x.device:
+        cached = (stamp, UniformPlan(N, indices, x.device))
         try:
             indices._hotk_uniform_plan = cached
         except AttributeError:
             pass
-    return cached
+    return cached[1]

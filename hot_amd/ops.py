@@ -33,18 +33,79 @@ def mask_rows(src, kind, keep, fill=0.0):
     return out
 
 
-def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID):
+_REFINED = {}
+
+
+def refine_seg(seg):
+    """Segments longer than SEG_CHUNK cut into consecutive pieces of at most SEG_CHUNK positions.
+    -> (fine, group): `fine` = the pieces as a segment list over the same positions (same perm), `group` = for every
+    original segment the contiguous range of its pieces (a segment list over the rows of a per-piece partial result).
+    Summing `fine` and then `group` adds every segment in a fixed order without atomics; a segment with more than
+    SEG_CHUNK pieces is refined again by the caller.  Index bookkeeping (torch ops + ONE host read of the piece count),
+    cached per segment list."""
     beg, end, perm, maxlen = seg
-    s, ld, n, C = rows2d(src)
+    key = (beg.data_ptr(), end.data_ptr(), beg.numel(), int(maxlen))
+    hit = _REFINED.get(key)
+    if hit is not None:
+        return hit[1], hit[2]
+    if len(_REFINED) > 64:
+        _REFINED.clear()
     n_seg = beg.numel()
-    alloc = torch.zeros if maxlen > SEG_CHUNK else torch.empty
-    out = alloc(n_seg, C, dtype=src.dtype, device=src.device)
-    call('hotk_seg_sum_rows', 4 * C * (n + n_seg), p(s), ld, p(beg), p(end), p(perm), p(kind), keep, p(out), C, n_seg, C, maxlen)
+    length = (end.long() - beg.long()).clamp_min(0)
+    pieces = (length + SEG_CHUNK - 1) // SEG_CHUNK
+    gend = torch.cumsum(pieces, 0)
+    gbeg = gend - pieces
+    total = int(gend[-1]) if n_seg else 0
+    owner = torch.repeat_interleave(torch.arange(n_seg, device=beg.device), pieces, output_size=total)
+    k = torch.arange(total, device=beg.device) - gbeg[owner]
+    vbeg = beg.long()[owner] + k * SEG_CHUNK
+    vend = torch.minimum(vbeg + SEG_CHUNK, end.long()[owner])
+    i32 = lambda t: t.to(torch.int32).contiguous()
+    fine = (i32(vbeg), i32(vend), perm, min(int(maxlen), SEG_CHUNK))
+    group = (i32(gbeg), i32(gend), None, int(pieces.max()) if n_seg else 0)
+    _REFINED[key] = ((beg, end), fine, group)      # the key tensors stay alive with the entry: pointers are not reused
+    return fine, group
+
+
+def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID, out=None):
+    """out[s] = sum of the kept rows of segment s, added in segment order (bitwise reproducible).  out: optional
+    destination (a column slice of a wider row-major tensor is fine)."""
+    beg, end, perm, maxlen = seg
+    n_seg = beg.numel()
+    if maxlen > SEG_CHUNK:
+        fine, group = refine_seg(seg)
+        part = seg_sum_rows(src, fine, kind, keep)
+        return seg_sum_rows(part, group, None, KEEP_VALID, out)
+    s, ld, n, C = rows2d(src)
+    if out is None:
+        out = torch.empty(n_seg, C, dtype=src.dtype, device=src.device)
+    o, ldo, no, Co = rows2d(out)
+    assert o.data_ptr() == out.data_ptr() and no == n_seg and Co == C, 'seg_sum_rows: destination is not row-major'
+    call('hotk_seg_sum_rows', 4 * C * (n + n_seg), p(s), ld, p(beg), p(end), p(perm), p(kind), keep, p(o), ldo, n_seg, C, maxlen)
     return out
+
+
+def bias_grads(g, kind, want_off, want_diag):
+    """(db_off, db_diag) = column sums of g over the off-diagonal / diagonal rows (hotk_bias_grad_rows: two passes,
+    bitwise reproducible)"""
+    gs, ld, n, C = rows2d(g)
+    db_off = torch.empty(C, dtype=g.dtype, device=g.device) if want_off else None
+    db_diag = torch.empty(C, dtype=g.dtype, device=g.device) if want_diag else None
+    if db_off is None and db_diag is None:
+        return None, None
+    need = c_size_t(0)
+    check(lib().hotk_bias_grad_workspace_bytes(n, C, byref(need)), 'hotk_bias_grad_workspace_bytes')
+    ws = torch.empty(max(need.value, 16), dtype=torch.uint8, device=g.device)
+    call('hotk_bias_grad_rows', 4 * n * C, p(gs), ld, p(kind), p(db_off), p(db_diag), n, C, p(ws), need.value)
+    return db_off, db_diag
 
 
 def seg_outer_sum(K, kidx, V, vidx, aug, seg, HH, m, c):
     beg, end, perm, maxlen = seg
+    if maxlen > SEG_CHUNK:      # per-piece partial sums, then added per segment in piece order: no atomics
+        fine, group = refine_seg(seg)
+        part = seg_outer_sum(K, kidx, V, vidx, aug, fine, HH, m, c)
+        return seg_sum_rows(part.view(part.size(0), -1), group).view(beg.numel(), HH * m, c + 1)
     k, ldk, _, Ck = rows2d(K)
     v, ldv, _, Cv = rows2d(V)
     assert Ck == HH * m and Cv == HH * c, (Ck, Cv, HH, m, c)
@@ -54,8 +115,7 @@ def seg_outer_sum(K, kidx, V, vidx, aug, seg, HH, m, c):
     else:
         a, lda = None, 0
     n_seg = beg.numel()
-    alloc = torch.zeros if maxlen > SEG_CHUNK else torch.empty
-    KV = alloc(n_seg, HH * m, c + 1, dtype=K.dtype, device=K.device)
+    KV = torch.empty(n_seg, HH * m, c + 1, dtype=K.dtype, device=K.device)
     call('hotk_seg_outer_sum', 4 * (v.numel() // max(Cv, 1)) * (Ck + Cv) + 4 * KV.numel(), p(k), ldk, p(kidx), p(v), ldv, p(vidx), p(a), lda, p(beg), p(end), p(perm), p(KV),
                                    n_seg, HH, m, c, maxlen)
     return KV
@@ -358,12 +418,10 @@ class Linear22Light(Function):
         if plan.Ev != plan.R:
             g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)      # padding rows of an upstream gradient may hold anything
         # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
-        long_seg = max(plan.max_row_deg, plan.max_col_deg) > SEG_CHUNK
-        dyn = (torch.zeros if long_seg else torch.empty)(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
+        dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
         call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-        for k, (beg, end, perm, maxlen) in ((1, plan.row_seg()), (2, plan.col_seg())):
-            call('hotk_seg_sum_rows', 4 * C * (plan.Ev + plan.Nn), p(g), C, p(beg), p(end), p(perm), p(plan.kind),
-                 KEEP_OFFDIAG, c_void_p_of(dyn, k * C), 3 * C, plan.Nn, C, maxlen)
+        seg_sum_rows(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
+        seg_sum_rows(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
         # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
         # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows
         db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
@@ -408,12 +466,10 @@ class Assemble12(Function):
         g = g.contiguous().view(plan.R, C)
         if plan.Ev != plan.R:
             g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
-        long_seg = max(plan.max_row_deg, plan.max_col_deg) > SEG_CHUNK
-        dyn = (torch.zeros if long_seg else torch.empty)(plan.Nn, 3 * C, dtype=g.dtype, device=g.device)
+        dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=g.device)
         call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-        for k, (beg, end, perm, maxlen) in ((1, plan.row_seg()), (2, plan.col_seg())):
-            call('hotk_seg_sum_rows', 4 * C * (plan.Ev + plan.Nn), p(g), C, p(beg), p(end), p(perm), p(plan.kind),
-                 KEEP_OFFDIAG, c_void_p_of(dyn, k * C), 3 * C, plan.Nn, C, maxlen)
+        seg_sum_rows(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
+        seg_sum_rows(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
         db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
         db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
         return dyn, db_off, db_diag, None
@@ -438,10 +494,7 @@ class BiasMask(Function):
     def backward(ctx, g):
         (kind,) = ctx.saved_tensors
         gs, ld, n, C = rows2d(g)
-        db_off = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[0] else None
-        db_diag = torch.zeros(C, dtype=g.dtype, device=g.device) if ctx.has[1] else None
-        if db_off is not None or db_diag is not None:
-            call('hotk_bias_grad_rows', 4 * n * C, p(gs), ld, p(kind), p(db_off), p(db_diag), n, C)
+        db_off, db_diag = bias_grads(g, kind, ctx.has[0], ctx.has[1])
         return (g if ctx.no_pad else mask_rows(g, kind, KEEP_VALID, 0.0)), None, db_off, db_diag, None
 
 
@@ -774,7 +827,9 @@ class AttnCore22(Function):
         ws, nws = AttnCore22._workspace(plan, dev)
         shard = getattr(plan, 'shard', None)
         if shard is None:
-            call('hotk_attn22_backward', 4 * plan.Ev * (8 * 32 * 2 + 10 * 32 * 3 + 6 * 32) + 4 * plan.Nn * 384 * 2,
+            # algorithmic bytes as SURVEY 8d counts them: read h2, v, datt, write dh2, dv (+ indices); the per-entry key
+            # gradients ck are this implementation's scratch, not algorithmic traffic
+            call('hotk_attn22_backward', plan.Ev * (4 * (8 * 32 * 2 + 10 * 32 * 3) + 25) + 4 * plan.Nn * 384 * 2,
                  byref(a), p(ws), nws)
         else:
             # backward of the forward all-reduces: every rank needs the full d(sums) before its key / value side
@@ -788,11 +843,7 @@ class AttnCore22(Function):
             shard.all_reduce_(dkvn)
             AttnCore22._phase(a, _lib.ATTN22_BWD_KEYVAL, ws, nws, 4 * plan.Ev * (10 * 32 * 2 + 8 * 32 + 2 * 32) + 4 * kvn.numel())
         # d(raw key slots 0..5 of node i) = sum over the entries of row i of their per-entry contributions
-        beg, end, perm, maxlen = plan.row_seg()
-        if maxlen > SEG_CHUNK:
-            dh1[:, 128:320].zero_()
-        call('hotk_seg_sum_rows', 4 * 192 * (plan.Ev + plan.Nn), p(ck), 192, p(beg), p(end), p(perm), p(None),
-             KEEP_VALID, c_void_p_of(dh1, 128), 384, plan.Nn, 192, maxlen)
+        seg_sum_rows(ck, plan.row_seg(), None, KEEP_VALID, out=dh1[:, 128:320])
         return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None, None, None
 
 

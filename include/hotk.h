@@ -80,8 +80,9 @@ int hotk_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, float
 int hotk_mask_rows(const float* src, int64_t ld_src, const uint8_t* kind, unsigned keep, float fill,
                    float* out, int64_t ld_out, int64_t n, int64_t C, void* stream);
 /* out[s] = sum over p in [seg_begin[s], seg_end[s]) of src[perm[p]] restricted to kinds in `keep`
- * (perm NULL = identity, kind NULL = no filter).  `out` must be zero-filled by the caller when
- * max_seg_len > HOTK_SEG_CHUNK (long segments are split and combined with float atomics).
+ * (perm NULL = identity, kind NULL = no filter).  One thread adds the rows of a segment in segment order: bitwise
+ * reproducible, no atomics.  max_seg_len > HOTK_SEG_CHUNK returns HOTK_EUNSUPPORTED: the caller splits longer segments
+ * into consecutive pieces and sums the partial rows with a second call (hot_amd.ops.refine_seg does this).
  * replaces the M.float().bmm(values) poolings of models/sparse/linear.py:187-231 and scatter_add_
  * backward of the gathers. */
 #define HOTK_SEG_CHUNK 1024
@@ -92,9 +93,13 @@ int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t* seg_begin
  * (models/sparse/linear.py:297-306,345-346); order 1: pass nkind and b_diag (b_off may be NULL). */
 int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* b_off, const float* b_diag,
                         int64_t n, int64_t C, void* stream);
-/* db_off[c] = sum over kind-2 rows of dy, db_diag[c] = sum over kind-1 rows; outputs must be zeroed. */
+/* db_off[c] = sum over kind-2 rows of dy, db_diag[c] = sum over kind-1 rows (either may be NULL): gradients of the two
+ * _Bias vectors (models/sparse/linear.py:293-306).  Two passes (per-block partial rows in the workspace, then added in
+ * block order): bitwise reproducible, no atomics; outputs are overwritten.
+ * workspace: hotk_bias_grad_workspace_bytes(n, C). */
+int hotk_bias_grad_workspace_bytes(int64_t n, int64_t C, size_t* bytes);
 int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* kind, float* db_off, float* db_diag,
-                        int64_t n, int64_t C, void* stream);
+                        int64_t n, int64_t C, void* workspace, size_t ws_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * K4  order-2 equivariant basis, 'light' configuration (models/sparse/linear.py:143-161):
@@ -174,7 +179,8 @@ int hotk_phi_key_bwd_stats(const float* x, int64_t ld_x, const float* proj, cons
  * ---------------------------------------------------------------------------------------------- */
 /* KV[s][f][ch] = sum_{p in seg s} K[kidx[e]][f] * (ch<c ? V[vidx[e]][hh*c+ch] : AUG[e][hh] or 1), e = perm[p].
  * kidx/vidx/perm NULL = identity; vidx[e] < 0 contributes zeros to the value channels only.
- * KV must be zero-filled when max_seg_len > HOTK_SEG_CHUNK. */
+ * Segment order, no atomics; max_seg_len > HOTK_SEG_CHUNK returns HOTK_EUNSUPPORTED (split the segments and add the
+ * partial sums with hotk_seg_sum_rows, as hot_amd.ops.seg_outer_sum does). */
 int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* kidx, const float* V, int64_t ld_v,
                        const int32_t* vidx, const float* aug, int64_t ld_aug, const int32_t* seg_begin,
                        const int32_t* seg_end, const int32_t* perm, float* KV, int64_t n_seg, int HH, int m,

@@ -303,6 +303,13 @@ def test_uniform_extension_vs_reference(name):
     bad[0, 1] = bad[0, 0]
     with pytest.raises(AssertionError):
         enc(x0, bad)
+    # the cached plan follows an in-place refill of the same indices buffer
+    lin = ULinear(1, k, D, 6, cfg='light').to(DEV)
+    buf = idx.clone()
+    y1 = lin(x0, buf).clone()
+    buf.copy_(idx.flip(0))
+    y2 = lin(x0, buf)
+    assert torch.equal(y2, y1.flip(0))
 
 
 @pytest.mark.parametrize('K,C', [(64, 288), (32, 320), (288, 64), (320, 32), (64, 96)])
@@ -567,3 +574,58 @@ def test_full_size_replication_property():
     assert e_rep_y < 1e-6 and e_rep_g < 1e-6
     yo = O.kernel_self_attn(GO, sd, 2, 2, 32, 32, 32, 4, 'default', True)
     assert rel_err(yv[0].cpu(), yo.values.detach()) < TOL
+
+
+def test_long_segments_and_bias_gradients_are_reproducible():
+    """Segments longer than HOTK_SEG_CHUNK (1024) and the bias gradients used to be combined with float atomics; they
+    are now summed in a fixed order (pieces of <= 1024 positions, partial rows added in piece order; per-block partial
+    rows added in block order).  Two runs must agree bit for bit, and with an fp64 sum to fp32 rounding."""
+    _lib, ops, *_ = _product()
+    g = torch.Generator().manual_seed(123)
+    n, C = 60000, 96
+    src = torch.randn(n, C, generator=g).to(DEV)
+    # segment lengths: empty, short, exactly one piece, just over, long (several pieces), and one above 1024 pieces
+    lens = [0, 7, 1024, 1025, 5000, 3, 0, 2500]
+    lens.append(n - sum(lens) - 10)                       # ~51 000 rows: 50 pieces
+    beg = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    end = (beg + np.asarray(lens)).astype(np.int32)
+    perm = torch.randperm(n, generator=g).to(torch.int32).to(DEV)
+    kind = torch.randint(0, 3, (n,), generator=g).to(torch.uint8).to(DEV)
+    seg = (torch.from_numpy(beg).to(DEV), torch.from_numpy(end).to(DEV), perm, max(lens))
+    outs = [ops.seg_sum_rows(src, seg, kind, _lib.KEEP_OFFDIAG) for _ in range(2)]
+    assert torch.equal(outs[0], outs[1])
+    ref = torch.zeros(len(lens), C, dtype=torch.float64)
+    sc, pc, kc = src.double().cpu(), perm.long().cpu(), kind.cpu()
+    for s_, (b_, e_) in enumerate(zip(beg, end)):
+        rows = pc[b_:e_]
+        ref[s_] = sc[rows][kc[rows] == 2].sum(0)
+    assert rel_err(outs[0].cpu(), ref.float()) < TOL
+    # ONE segment of 2.2 M rows: more than 1024 pieces, refined twice
+    big = torch.randn(2_200_000, 8, generator=g).to(DEV)
+    one = (torch.zeros(1, dtype=torch.int32, device=DEV), torch.full((1,), big.size(0), dtype=torch.int32, device=DEV),
+           None, big.size(0))
+    t1, t2 = ops.seg_sum_rows(big, one), ops.seg_sum_rows(big, one)
+    assert torch.equal(t1, t2) and rel_err(t1.cpu(), big.double().sum(0, keepdim=True).float().cpu()) < TOL
+    # key-value sums over long segments (general attention kernels)
+    HH, m, c = 4, 16, 8
+    K = torch.randn(n, HH * m, generator=g).to(DEV)
+    V = torch.randn(n, HH * c, generator=g).to(DEV)
+    kv = [ops.seg_outer_sum(K, None, V, None, None, seg, HH, m, c) for _ in range(2)]
+    assert torch.equal(kv[0], kv[1])
+    s_ = 4
+    rows = pc[beg[s_]:end[s_]]
+    Kd, Vd = K.double().cpu()[rows].view(-1, HH, m), V.double().cpu()[rows].view(-1, HH, c)
+    ref_kv = torch.cat([torch.einsum('ehm,ehc->hmc', Kd, Vd), Kd.sum(0).unsqueeze(-1)], -1).reshape(HH * m, c + 1)
+    assert rel_err(kv[0][s_].cpu(), ref_kv.float()) < TOL
+    # bias gradients
+    for rows_n, Cb in ((1_000_003, 288), (777, 32), (5000, 50)):
+        dy = torch.randn(rows_n, Cb, generator=g).to(DEV)
+        kd = torch.randint(0, 3, (rows_n,), generator=g).to(torch.uint8).to(DEV)
+        a = ops.bias_grads(dy, kd, True, True)
+        b = ops.bias_grads(dy, kd, True, True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        dd = dy.double()
+        assert rel_err(a[0].cpu(), dd[kd == 2].sum(0).float().cpu()) < TOL
+        assert rel_err(a[1].cpu(), dd[kd == 1].sum(0).float().cpu()) < TOL
+        only = ops.bias_grads(dy, kd, False, True)
+        assert only[0] is None and torch.equal(only[1], a[1])
