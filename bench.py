@@ -95,6 +95,132 @@ def cpu_baseline(n_graphs=192, threads=None):
                       f'oracle/hot_oracle.py on torch-CPU fp32'}
 
 
+def sweep(device, repeat=3, n_max=None):
+    """The reference's only published artefact restated (run_perf_tests.py:91-243, docs/linear-scaling.png): forward /
+    backward time and peak memory of a 4-layer sparse model on ONE Barabasi-Albert(n, 5) graph, n swept over
+    2^(5..18)/5, dim = dim_qk = dim_v = dim_ff = 32, 4 heads.  Curves: SK = Encoder(2,0,[2]*4,...,'generalized_kernel')
+    (fixed projections), SL = MLP(2,0,[2]*4) of Linear(cfg='default').  HIP events on the current stream, as the
+    reference's CUDA events; an own seeded BA generator stands in for networkx."""
+    from hot_amd.batch.sparse import make_batch
+    from hot_amd.models import Encoder, MLP
+    from hot_amd.utils.graphs import ba_edges
+    n_list = sorted(set(int(v) // 5 for v in 2 ** np.linspace(5, 18, 27, endpoint=True)))
+    n_list = [n for n in n_list if n > 5 and (n_max is None or n <= n_max)]
+    torch.manual_seed(0)
+    models = {
+        'SK': Encoder(2, 0, [2] * 4, 32, 32, 32, 32, 32, 32, 4, 32, 32, 4, 'default', 'generalized_kernel', 0., 0., 0.,
+                      sparse=True).to(device),
+        'SL': MLP(2, 0, [2] * 4, 32, 32, 32, sparse=True).to(device),
+    }
+    models['SK'].skip_redraw_projections = True
+    out = {k: [] for k in models}
+    for n in n_list:
+        for name, model in models.items():
+            ft, bt, pm, ne = [], [], [], 0
+            for i in range(repeat + 1):                      # first repetition = warm-up, dropped
+                rng = np.random.default_rng(i)
+                ei = torch.from_numpy(ba_edges(n, 5, rng)).to(device)
+                g = torch.Generator(device=device).manual_seed(i)
+                nf = torch.randn(n, 16, device=device, generator=g)
+                ef = torch.randn(ei.size(1), 16, device=device, generator=g)
+                G = make_batch([nf], [ei], [ef])
+                ne = sum(G.n_edges)
+                torch.cuda.synchronize()
+                torch.cuda.reset_peak_memory_stats()
+                e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+                e0.record()
+                y = model(G)
+                e1.record()
+                y.sum().backward()
+                e2.record()
+                torch.cuda.synchronize()
+                if i:
+                    ft.append(e0.elapsed_time(e1)); bt.append(e1.elapsed_time(e2))
+                    pm.append(torch.cuda.max_memory_allocated() / 2 ** 30)
+                model.zero_grad(set_to_none=True)
+                del G, y
+            out[name].append({'n': n, 'entries': ne, 'forward_ms': round(float(np.mean(ft)), 3),
+                              'backward_ms': round(float(np.mean(bt)), 3), 'peak_mem_GiB': round(float(np.mean(pm)), 4)})
+    return {'harness': 'run_perf_tests.py:221-243 restated: bsize 1, 4 layers, dim 32, 4 heads, BA(n,5), repeat %d' % repeat,
+            'curves': out}
+
+
+def edge_shard_mode(args, device, world, rank, dist):
+    """--mode edge-shard: ONE graph sharded by entries over the ranks.  Weak scaling: 125 000
+    nodes and 3.125 M undirected pairs per GPU, so that 8 GPUs hold exactly C5 (1 M nodes, 25 M pairs = 50 M directed
+    entries + 1 M diagonal).  Every rank generates the same graph from one seed and keeps its shard
+    (hot_amd.dist.shard_graph); the per-node / per-graph key-value sums are all-reduced over RCCL between the phases of
+    the fused core, parameter gradients at the end of the step."""
+    from hot_amd import _lib
+    from hot_amd.batch.sparse import batch_like
+    from hot_amd.dist import shard_graph, allreduce_gradients, max_over_ranks
+    n_nodes = args.shard_nodes * world
+    n_pairs = args.shard_pairs * world
+    g = torch.Generator(device=device).manual_seed(4321)
+    # unique unordered pairs (i < j) from random draws, duplicates dropped (a few per million)
+    i = torch.randint(0, n_nodes, (int(n_pairs * 1.02),), device=device, generator=g)
+    j = torch.randint(0, n_nodes, (int(n_pairs * 1.02),), device=device, generator=g)
+    lo, hi = torch.minimum(i, j), torch.maximum(i, j)
+    key = torch.unique((lo * n_nodes + hi)[lo != hi])[:n_pairs]
+    lo, hi = key // n_nodes, key % n_nodes
+    ei = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
+    order = torch.argsort(ei[0] * n_nodes + ei[1])
+    ei = ei[:, order].contiguous()
+    nf = torch.randn(n_nodes, D // 2, device=device, generator=g)
+    ef = torch.randn(ei.size(1), D // 2, device=device, generator=g)
+    group = None
+    G, own = shard_graph(nf, ei, ef, world, rank, group)
+    del nf, ef, i, j, lo, hi, key, order
+    layer = make_layer(device)
+    params = list(layer.parameters())
+    x0 = G.values
+    w = G.plan.shard.entry_weight.view(1, -1, 1)
+
+    def step():
+        x = x0.detach().requires_grad_(True)
+        out = layer(batch_like(G, x, skip_masking=True))
+        (out.values * w).sum().backward()          # replicated diagonal rows count once over the ranks
+        if dist is not None:
+            allreduce_gradients(params)
+        for p_ in params:
+            p_.grad = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    _lib.timing_begin(None)
+    step()
+    census = _lib.timing_end()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    n_total = n_nodes + ei.size(1)
+    local = int(G.plan.Ev)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': n_total * args.steps / elapsed,
+            'unit': 'entries/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'S5/C5 edge-shard: ONE graph, {n_nodes} nodes, {ei.size(1)} directed entries + diagonal, '
+                                   f'sharded by unordered pair over {world} GPU(s) ({local} local rows on rank 0); '
+                                   f'KernelSelfAttn(2,2,32,32,32,4) generalized FAVOR+, phased fused core + all-reduces',
+                       'entries_total': n_total, 'parallelism': f'edge-shard x{world}'},
+            'exchange_bytes_per_step_per_rank': 2 * 4 * (2 * G.plan.Nn * 1152 + G.plan.Nn * 128) if world > 1 else 0,
+            'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
+            'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -103,6 +229,11 @@ def main():
     ap.add_argument('--entries', type=float, default=10e6, help='entries per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-kernel', default='auto', help='C-ABI entry point timed live with HIP events')
+    ap.add_argument('--mode', default='graph-minibatch', choices=['graph-minibatch', 'edge-shard'])
+    ap.add_argument('--shard-nodes', type=int, default=125000, help='edge-shard mode: nodes per GPU')
+    ap.add_argument('--shard-pairs', type=int, default=3125000, help='edge-shard mode: undirected pairs per GPU')
+    ap.add_argument('--sweep', action='store_true', help='run_perf_tests.py-style size sweep (SK / SL curves) instead')
+    ap.add_argument('--sweep-max-n', type=int, default=None)
     args = ap.parse_args()
 
     if os.environ.get('HOTK_BENCH_DEBUG'):
@@ -129,6 +260,17 @@ def main():
     from hot_amd import _lib
     from hot_amd.batch.sparse import batch_like
     from hot_amd.dist import allreduce_gradients, max_over_ranks
+
+    if args.sweep:
+        if rank == 0:
+            print(json.dumps(sweep(device, n_max=args.sweep_max_n)), flush=True)
+        return
+    if args.mode == 'edge-shard':
+        edge_shard_mode(args, device, world, rank, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     n_graphs = max(1, int(round(args.entries / ENTRIES_PER_GRAPH)))
     G = make_inputs(n_graphs, device, seed=1234 + rank)

@@ -33,14 +33,16 @@ __global__ __launch_bounds__(64) void k_softmax_pool_fwd(const float* __restrict
                                                          const int32_t* __restrict__ seg_end,
                                                          const uint8_t* __restrict__ kind, unsigned keep,
                                                          float* __restrict__ out, int64_t ld_out,
-                                                         float* __restrict__ alpha, int64_t n_seg, int H, int d, int c) {
+                                                         float* __restrict__ alpha, float* __restrict__ stats,
+                                                         const int32_t* __restrict__ q_row, int64_t n_seg, int H, int d,
+                                                         int c) {
   const int lane = threadIdx.x;
   const float scale = rsqrtf((float)d);
   for (int64_t w = blockIdx.x; w < n_seg * H; w += gridDim.x) {
     const int64_t b = w / H;
     const int h = (int)(w - b * H);
     const int32_t r0 = seg_begin[b], r1 = seg_end[b];
-    const float* qh = q + b * ld_q + h * d;
+    const float* qh = q + (q_row ? (int64_t)q_row[b] : b) * ld_q + h * d;
     // pass 1: raw scores (-inf on rows that are not kept) and their maximum
     float mx = -INFINITY;
     for (int32_t r = r0 + lane; r < r1; r += 64) {
@@ -64,6 +66,10 @@ __global__ __launch_bounds__(64) void k_softmax_pool_fwd(const float* __restrict
       sum += e;
     }
     sum = wave_sum(sum);
+    if (stats && lane == 0) {      // (maximum, sum of exponentials) of this segment: lets a caller merge pieces of one set
+      stats[(b * H + h) * 2 + 0] = mx;
+      stats[(b * H + h) * 2 + 1] = sum;
+    }
     const float inv = sum > 0.f ? 1.f / sum : 0.f;
     // pass 3: normalise and pool the values, CT channels at a time
     for (int c0 = 0; c0 < c; c0 += CT) {
@@ -104,16 +110,18 @@ __global__ __launch_bounds__(64) void k_softmax_pool_bwd(const float* __restrict
                                                          int64_t ld_out, const float* __restrict__ dout, int64_t ld_dout,
                                                          float* __restrict__ dq, int64_t ld_dq, float* __restrict__ dk,
                                                          int64_t ld_dk, float* __restrict__ dv, int64_t ld_dv,
-                                                         int64_t n_seg, int H, int d, int c) {
+                                                         const int32_t* __restrict__ q_row, int64_t n_seg, int H, int d,
+                                                         int c) {
   const int lane = threadIdx.x;
   const float scale = rsqrtf((float)d);
   for (int64_t w = blockIdx.x; w < n_seg * H; w += gridDim.x) {
     const int64_t b = w / H;
     const int h = (int)(w - b * H);
     const int32_t r0 = seg_begin[b], r1 = seg_end[b];
-    const float* qh = q + b * ld_q + h * d;
-    const float* gh = dout + b * ld_dout + h * c;
-    const float* oh = out + b * ld_out + h * c;
+    const int64_t bq = q_row ? (int64_t)q_row[b] : b;      // row of q / out / dout this segment belongs to
+    const float* qh = q + bq * ld_q + h * d;
+    const float* gh = dout + bq * ld_dout + h * c;
+    const float* oh = out + bq * ld_out + h * c;
     float dot = 0.f;
     for (int t = 0; t < c; ++t) dot = fmaf(gh[t], oh[t], dot);
     // d q_h is accumulated CT components at a time (the per-row ds is recomputed for every tile)
@@ -153,13 +161,14 @@ __global__ __launch_bounds__(64) void k_softmax_pool_bwd(const float* __restrict
 extern "C" int hotk_seg_softmax_pool_fwd(const float* q, int64_t ld_q, const float* k, int64_t ld_k, const float* v,
                                          int64_t ld_v, const int32_t* seg_begin, const int32_t* seg_end,
                                          const uint8_t* kind, unsigned keep, float* out, int64_t ld_out, float* alpha,
-                                         int64_t n_seg, int H, int d, int c, void* stream) {
+                                         float* stats, const int32_t* q_row, int64_t n_seg, int H, int d, int c,
+                                         void* stream) {
   HOTK_CHECK_ARG(n_seg >= 0 && H > 0 && d > 0 && c > 0 && ld_q >= (int64_t)H * d && ld_k >= (int64_t)H * d &&
                  ld_v >= (int64_t)H * c && ld_out >= (int64_t)H * c);
   if (n_seg == 0) return HOTK_OK;
   HOTK_CHECK_ARG(q && k && v && seg_begin && seg_end && kind && out && alpha);
   hipLaunchKernelGGL(k_softmax_pool_fwd, dim3(hotk_grid(n_seg * H, 1, 256 * 64)), dim3(64), 0, (hipStream_t)stream, q,
-                     ld_q, k, ld_k, v, ld_v, seg_begin, seg_end, kind, keep, out, ld_out, alpha, n_seg, H, d, c);
+                     ld_q, k, ld_k, v, ld_v, seg_begin, seg_end, kind, keep, out, ld_out, alpha, stats, q_row, n_seg, H, d, c);
   return hotk_launch_status();
 }
 
@@ -167,7 +176,8 @@ extern "C" int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const flo
                                          int64_t ld_v, const int32_t* seg_begin, const int32_t* seg_end,
                                          const float* alpha, const float* out, int64_t ld_out, const float* dout,
                                          int64_t ld_dout, float* dq, int64_t ld_dq, float* dk, int64_t ld_dk, float* dv,
-                                         int64_t ld_dv, int64_t n_seg, int H, int d, int c, void* stream) {
+                                         int64_t ld_dv, const int32_t* q_row, int64_t n_seg, int H, int d, int c,
+                                         void* stream) {
   HOTK_CHECK_ARG(n_seg >= 0 && H > 0 && d > 0 && c > 0 && ld_q >= (int64_t)H * d && ld_k >= (int64_t)H * d &&
                  ld_v >= (int64_t)H * c && ld_out >= (int64_t)H * c && ld_dout >= (int64_t)H * c &&
                  ld_dq >= (int64_t)H * d && ld_dk >= (int64_t)H * d && ld_dv >= (int64_t)H * c);
@@ -175,6 +185,6 @@ extern "C" int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const flo
   HOTK_CHECK_ARG(q && k && v && seg_begin && seg_end && alpha && out && dout && dq && dk && dv);
   hipLaunchKernelGGL(k_softmax_pool_bwd, dim3(hotk_grid(n_seg * H, 1, 256 * 64)), dim3(64), 0, (hipStream_t)stream, q,
                      ld_q, k, ld_k, v, ld_v, seg_begin, seg_end, alpha, out, ld_out, dout, ld_dout, dq, ld_dq, dk, ld_dk,
-                     dv, ld_dv, n_seg, H, d, c);
+                     dv, ld_dv, q_row, n_seg, H, d, c);
   return hotk_launch_status();
 }

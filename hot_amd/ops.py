@@ -34,17 +34,19 @@ def mask_rows(src, kind, keep, fill=0.0):
 
 
 _REFINED = {}
+SEG_SPLIT = 256        # rows one thread adds at most (<= the ABI's HOTK_SEG_CHUNK)
+POOL_SPLIT = 2048      # rows one wavefront of the softmax-pooling kernel walks at most
 
 
-def refine_seg(seg):
-    """Segments longer than SEG_CHUNK cut into consecutive pieces of at most SEG_CHUNK positions.
+def refine_seg(seg, chunk=SEG_CHUNK):
+    """Segments longer than `chunk` cut into consecutive pieces of at most `chunk` positions.
     -> (fine, group): `fine` = the pieces as a segment list over the same positions (same perm), `group` = for every
     original segment the contiguous range of its pieces (a segment list over the rows of a per-piece partial result).
     Summing `fine` and then `group` adds every segment in a fixed order without atomics; a segment with more than
     SEG_CHUNK pieces is refined again by the caller.  Index bookkeeping (torch ops + ONE host read of the piece count),
     cached per segment list."""
     beg, end, perm, maxlen = seg
-    key = (beg.data_ptr(), end.data_ptr(), beg.numel(), int(maxlen))
+    key = (beg.data_ptr(), end.data_ptr(), beg.numel(), int(maxlen), int(chunk))
     hit = _REFINED.get(key)
     if hit is not None:
         return hit[1], hit[2]
@@ -52,19 +54,29 @@ def refine_seg(seg):
         _REFINED.clear()
     n_seg = beg.numel()
     length = (end.long() - beg.long()).clamp_min(0)
-    pieces = (length + SEG_CHUNK - 1) // SEG_CHUNK
+    pieces = (length + chunk - 1) // chunk
     gend = torch.cumsum(pieces, 0)
     gbeg = gend - pieces
     total = int(gend[-1]) if n_seg else 0
     owner = torch.repeat_interleave(torch.arange(n_seg, device=beg.device), pieces, output_size=total)
     k = torch.arange(total, device=beg.device) - gbeg[owner]
-    vbeg = beg.long()[owner] + k * SEG_CHUNK
-    vend = torch.minimum(vbeg + SEG_CHUNK, end.long()[owner])
+    vbeg = beg.long()[owner] + k * chunk
+    vend = torch.minimum(vbeg + chunk, end.long()[owner])
     i32 = lambda t: t.to(torch.int32).contiguous()
-    fine = (i32(vbeg), i32(vend), perm, min(int(maxlen), SEG_CHUNK))
+    fine = (i32(vbeg), i32(vend), perm, min(int(maxlen), int(chunk)))
     group = (i32(gbeg), i32(gend), None, int(pieces.max()) if n_seg else 0)
-    _REFINED[key] = ((beg, end), fine, group)      # the key tensors stay alive with the entry: pointers are not reused
+    group_owner = i32(owner)          # piece -> original segment
+    fine = fine + (group_owner,)
+    fine = fine[:4]
+    _REFINED[key] = ((beg, end), fine, group, group_owner)      # the key tensors stay alive with the entry: pointers are not reused
     return fine, group
+
+
+def refined_owner(seg, chunk):
+    """piece -> original segment (int32) of refine_seg(seg, chunk)"""
+    refine_seg(seg, chunk)
+    beg, end, perm, maxlen = seg
+    return _REFINED[(beg.data_ptr(), end.data_ptr(), beg.numel(), int(maxlen), int(chunk))][3]
 
 
 def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID, out=None):
@@ -72,8 +84,10 @@ def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID, out=None):
     destination (a column slice of a wider row-major tensor is fine)."""
     beg, end, perm, maxlen = seg
     n_seg = beg.numel()
-    if maxlen > SEG_CHUNK:
-        fine, group = refine_seg(seg)
+    if maxlen > SEG_SPLIT:
+        # one thread walks a segment: hub nodes and whole-graph segments are cut into pieces of SEG_SPLIT rows (more
+        # threads, same fixed order: piece sums, then the pieces of a segment in piece order)
+        fine, group = refine_seg(seg, SEG_SPLIT)
         part = seg_sum_rows(src, fine, kind, keep)
         return seg_sum_rows(part, group, None, KEEP_VALID, out)
     s, ld, n, C = rows2d(src)
@@ -102,8 +116,8 @@ def bias_grads(g, kind, want_off, want_diag):
 
 def seg_outer_sum(K, kidx, V, vidx, aug, seg, HH, m, c):
     beg, end, perm, maxlen = seg
-    if maxlen > SEG_CHUNK:      # per-piece partial sums, then added per segment in piece order: no atomics
-        fine, group = refine_seg(seg)
+    if maxlen > SEG_SPLIT:      # per-piece partial sums, then added per segment in piece order: no atomics
+        fine, group = refine_seg(seg, SEG_SPLIT)
         part = seg_outer_sum(K, kidx, V, vidx, aug, fine, HH, m, c)
         return seg_sum_rows(part.view(part.size(0), -1), group).view(beg.numel(), HH * m, c + 1)
     k, ldk, _, Ck = rows2d(K)
@@ -579,22 +593,51 @@ class KernelAttn(Function):
 class SoftmaxPool(Function):
     """Per-graph softmax attention with a zeroth-order query: out[b] = sum_r softmax_r(q_b . k_r / sqrt(d)) v_r over the
     kept rows of graph b, per head.  Stands in for AttnCoef._vector_query + apply_attn(k = 0)
-    (models/sparse/attncoef.py:25-59,165-173)."""
+    (models/sparse/attncoef.py:25-59,165-173).  One wavefront walks a segment; graphs with more than POOL_SPLIT rows
+    are cut into pieces whose results are merged exactly (piece maximum and sum of exponentials: the usual split
+    softmax), so a single giant graph spreads over the chip."""
 
     @staticmethod
     def forward(ctx, q, k, v, seg, kind, keep, H):
-        beg, end, _, _ = seg
+        beg, end, _, maxlen = seg
         qs, ldq, nb, Cq = rows2d(q)
         ks, ldk, n, Ck = rows2d(k)
         vs, ldv, nv, Cv = rows2d(v)
         assert Cq == Ck and nv == n and nb == beg.numel() and Cq % H == 0 and Cv % H == 0 and kind.numel() == n
         d, c = Cq // H, Cv // H
-        out = torch.empty(nb, Cv, dtype=q.dtype, device=q.device)
-        alpha = torch.zeros(n, H, dtype=q.dtype, device=q.device)
-        call('hotk_seg_softmax_pool_fwd', 4 * n * (Ck + Cv), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end), p(kind),
-             keep, p(out), Cv, p(alpha), nb, H, d, c)
+        dev = q.device
+        alpha = torch.zeros(n, H, dtype=q.dtype, device=dev)
+        split = maxlen > POOL_SPLIT
+        if not split:
+            out = torch.empty(nb, Cv, dtype=q.dtype, device=dev)
+            call('hotk_seg_softmax_pool_fwd', 4 * n * (Ck + Cv), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end), p(kind),
+                 keep, p(out), Cv, p(alpha), p(None), p(None), nb, H, d, c)
+            owner = fine = group = None
+        else:
+            fine, group = refine_seg(seg, POOL_SPLIT)
+            owner = refined_owner(seg, POOL_SPLIT)
+            fb, fe = fine[0], fine[1]
+            npc = fb.numel()
+            outp = torch.empty(npc, Cv, dtype=q.dtype, device=dev)
+            stats = torch.empty(npc, H, 2, dtype=q.dtype, device=dev)
+            call('hotk_seg_softmax_pool_fwd', 4 * n * (Ck + Cv), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(fb), p(fe), p(kind),
+                 keep, p(outp), Cv, p(alpha), p(stats), p(owner), npc, H, d, c)
+            # merge: weight of piece p in its graph = s_p e^(m_p - M) / sum_q s_q e^(m_q - M)   (tiny [pieces, H] tensors)
+            own = owner.long()
+            m_p, s_p = stats[..., 0], stats[..., 1]
+            M = torch.full((nb, H), float('-inf'), dtype=q.dtype, device=dev).scatter_reduce(
+                0, own.unsqueeze(1).expand(-1, H), m_p, 'amax', include_self=True)
+            w = torch.where(s_p > 0, s_p * torch.exp(m_p - M[own]), torch.zeros_like(s_p))
+            Z = seg_sum_rows(w, group)
+            wn = torch.where(Z[own] > 0, w / Z[own], torch.zeros_like(w))                       # [pieces, H]
+            out = seg_sum_rows((outp.view(npc, H, c) * wn.unsqueeze(-1)).view(npc, Cv), group)
+            # alpha of a row = its within-piece softmax weight x the weight of its piece
+            piece_of_row = torch.repeat_interleave(torch.arange(npc, device=dev), (fe - fb).long())
+            row_ids = _piece_rows(fb, fe)
+            alpha[row_ids] = alpha[row_ids] * wn[piece_of_row]
         ctx.save_for_backward(qs, ks, vs, alpha, out, beg, end)
         ctx.cfg = (ldq, ldk, ldv, nb, n, H, d, c, q.shape, k.shape, v.shape)
+        ctx.split = (fine, group, owner) if split else None
         return out
 
     @staticmethod
@@ -602,12 +645,29 @@ class SoftmaxPool(Function):
         qs, ks, vs, alpha, out, beg, end = ctx.saved_tensors
         ldq, ldk, ldv, nb, n, H, d, c, qshape, kshape, vshape = ctx.cfg
         g = g.contiguous()
-        dq = torch.zeros(nb, H * d, dtype=g.dtype, device=g.device)
         dk = torch.zeros(n, H * d, dtype=g.dtype, device=g.device)
         dv = torch.zeros(n, H * c, dtype=g.dtype, device=g.device)
-        call('hotk_seg_softmax_pool_bwd', 4 * n * 2 * H * (d + c), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end),
-             p(alpha), p(out), H * c, p(g), H * c, p(dq), H * d, p(dk), H * d, p(dv), H * c, nb, H, d, c)
+        if ctx.split is None:
+            dq = torch.zeros(nb, H * d, dtype=g.dtype, device=g.device)
+            call('hotk_seg_softmax_pool_bwd', 4 * n * 2 * H * (d + c), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end),
+                 p(alpha), p(out), H * c, p(g), H * c, p(dq), H * d, p(dk), H * d, p(dv), H * c, p(None), nb, H, d, c)
+        else:
+            fine, group, owner = ctx.split
+            npc = fine[0].numel()
+            dqp = torch.zeros(npc, H * d, dtype=g.dtype, device=g.device)
+            call('hotk_seg_softmax_pool_bwd', 4 * n * 2 * H * (d + c), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(fine[0]), p(fine[1]),
+                 p(alpha), p(out), H * c, p(g), H * c, p(dqp), H * d, p(dk), H * d, p(dv), H * c, p(owner), npc, H, d, c)
+            dq = seg_sum_rows(dqp, group)
         return dq.view(qshape), dk.view(kshape), dv.view(vshape), None, None, None, None
+
+
+def _piece_rows(fb, fe):
+    """row ids covered by the pieces [fb[p], fe[p]), piece after piece"""
+    length = (fe - fb).long()
+    start = torch.cumsum(length, 0) - length
+    total = int(length.sum())
+    piece = torch.repeat_interleave(torch.arange(fb.numel(), device=fb.device), length, output_size=total)
+    return fb.long()[piece] + (torch.arange(total, device=fb.device) - start[piece])
 
 
 def _ptr(t):

@@ -209,14 +209,20 @@ int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const
  *   alpha = softmax over those rows (0 elsewhere, all 0 for an empty set); out[b][h*c+ch] = sum_r alpha[r][h] v[r][h*c+ch].
  * alpha [n_rows, H] is written for the rows inside segments (caller zero-fills) and feeds the backward pass, which
  * writes dq [n_seg, H*d] and the kept rows of dk / dv (caller zero-fills those too).
+ * One wavefront walks a segment, so a very long set (one giant graph) is split by the caller into pieces: q_row[s] (may
+ * be NULL = s) names the row of q / out / dout that piece s belongs to, stats [n_seg, H, 2] (may be NULL) receives each
+ * piece's (maximum score, sum of exponentials) from which the caller merges the pieces' out and alpha exactly
+ * (hot_amd.ops.SoftmaxPool); the backward pass takes the MERGED alpha / out and yields per-piece partial dq rows.
  * ---------------------------------------------------------------------------------------------- */
 int hotk_seg_softmax_pool_fwd(const float* q, int64_t ld_q, const float* k, int64_t ld_k, const float* v, int64_t ld_v,
                               const int32_t* seg_begin, const int32_t* seg_end, const uint8_t* kind, unsigned keep,
-                              float* out, int64_t ld_out, float* alpha, int64_t n_seg, int H, int d, int c, void* stream);
+                              float* out, int64_t ld_out, float* alpha, float* stats, const int32_t* q_row,
+                              int64_t n_seg, int H, int d, int c, void* stream);
 int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int64_t ld_k, const float* v, int64_t ld_v,
                               const int32_t* seg_begin, const int32_t* seg_end, const float* alpha, const float* out,
                               int64_t ld_out, const float* dout, int64_t ld_dout, float* dq, int64_t ld_dq, float* dk,
-                              int64_t ld_dk, float* dv, int64_t ld_dv, int64_t n_seg, int H, int d, int c, void* stream);
+                              int64_t ld_dk, float* dv, int64_t ld_dv, const int32_t* q_row, int64_t n_seg, int H, int d,
+                              int c, void* stream);
 
 /* Backward of a narrow-input linear layer y[R, C] = x[R, K] @ W[K, C] + b in one pass over g = dy [R, C]
  * (nn.Linear fc_v of models/sparse/kernelattn.py:51,65-68 under autograd; the reference gets the three gradients from

@@ -629,3 +629,55 @@ def test_long_segments_and_bias_gradients_are_reproducible():
         assert rel_err(a[1].cpu(), dd[kd == 1].sum(0).float().cpu()) < TOL
         only = ops.bias_grads(dy, kd, False, True)
         assert only[0] is None and torch.equal(only[1], a[1])
+
+
+def test_softmax_pool_split_over_long_segments():
+    """The order-0 readout on graphs longer than one wavefront's walk: segments are cut into pieces, each piece is
+    pooled by one wavefront and the pieces are merged with their (maximum, sum of exponentials) -- the same numbers as
+    the one-piece kernel and as an fp64 softmax, forward and backward; includes an empty graph and a graph with no kept
+    row inside one of its pieces."""
+    _lib, ops, *_ = _product()
+    g = torch.Generator().manual_seed(5)
+    H, d, c = 4, 8, 8
+    lens = [3000, 0, 70, 9001, 2048]
+    n = sum(lens)
+    beg = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+    end = (beg + np.asarray(lens)).astype(np.int32)
+    seg = (torch.from_numpy(beg).to(DEV), torch.from_numpy(end).to(DEV), None, max(lens))
+    kind = torch.randint(1, 3, (n,), generator=g).to(torch.uint8)
+    kind[3070:3070 + 2100] = 1                              # a whole piece of graph 3 without a kept row
+    kind = kind.to(DEV)
+    q0 = torch.randn(len(lens), H * d, generator=g).to(DEV)
+    k0 = (2 * torch.randn(n, H * d, generator=g)).to(DEV)
+    v0 = torch.randn(n, H * c, generator=g).to(DEV)
+    R = torch.randn(len(lens), H * c, generator=g).to(DEV)
+    res = []
+    for split in (1 << 30, 1024):
+        ops.POOL_SPLIT = split
+        try:
+            q, k, v = (t.clone().requires_grad_(True) for t in (q0, k0, v0))
+            out = ops.SoftmaxPool.apply(q, k, v, seg, kind, _lib.KEEP_OFFDIAG, H)
+            (out * R).sum().backward()
+            res.append((out.detach(), q.grad, k.grad, v.grad))
+        finally:
+            ops.POOL_SPLIT = 2048
+    for a_, b_ in zip(*res):
+        assert rel_err(a_.cpu(), b_.cpu()) < TOL
+    # fp64 statement
+    qd, kd, vd = (t.double().cpu().requires_grad_(True) for t in (q0, k0, v0))
+    outs = []
+    keepm = (kind.cpu() == 2)
+    for b_, e_, s_ in zip(beg, end, range(len(lens))):
+        kk, vv, mm = kd[b_:e_].view(-1, H, d), vd[b_:e_].view(-1, H, c), keepm[b_:e_]
+        sc = torch.einsum('hd,rhd->rh', qd[s_].view(H, d), kk) / d ** 0.5
+        sc = sc.masked_fill(~mm.unsqueeze(1), float('-inf'))
+        al = torch.softmax(sc, 0) if bool(mm.any()) else torch.zeros_like(sc)
+        al = al.masked_fill(~mm.unsqueeze(1), 0)
+        outs.append(torch.einsum('rh,rhc->hc', al, vv).reshape(-1))
+    ref = torch.stack(outs)
+    (ref * R.double().cpu()).sum().backward()
+    out, gq, gk, gv = res[1]
+    assert rel_err(out.cpu(), ref.detach().float()) < TOL
+    assert rel_err(gq.cpu(), qd.grad.float()) < 2 * TOL
+    assert rel_err(gk.cpu(), kd.grad.float()) < 2 * TOL
+    assert rel_err(gv.cpu(), vd.grad.float()) < 2 * TOL
