@@ -230,6 +230,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-kernel', default='auto', help='C-ABI entry point timed live with HIP events')
     ap.add_argument('--mode', default='graph-minibatch', choices=['graph-minibatch', 'edge-shard'])
+    ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
+                    help="bf16: the layer's bf16 STORAGE mode (wide intermediates in bf16, fp32 accumulation; tolerance "
+                         "2e-2). A second line, never the headline: the reference trains in fp32")
     ap.add_argument('--shard-nodes', type=int, default=125000, help='edge-shard mode: nodes per GPU')
     ap.add_argument('--shard-pairs', type=int, default=3125000, help='edge-shard mode: undirected pairs per GPU')
     ap.add_argument('--sweep', action='store_true', help='run_perf_tests.py-style size sweep (SK / SL curves) instead')
@@ -284,7 +287,7 @@ def main():
     Plan(G.indices, G.n_nodes, G.n_edges)
     torch.cuda.synchronize()
     k1_ms = (time.perf_counter() - t_k1) * 1e3
-    layer = make_layer(device)
+    layer = make_layer(device).set_storage(args.storage)
     params = [p for p in layer.parameters()]
     x0 = G.values
 
@@ -328,7 +331,8 @@ def main():
     value = total_entries * args.steps / elapsed
 
     if rank == 0:
-        bpe = BYTES_PER_ENTRY + BYTES_PER_NODE * sum(G.n_nodes) / n_entries
+        bpe_entry = BYTES_PER_ENTRY if args.storage == 'f32' else (96 * DQK + 224 * DV) // 2 + 50
+        bpe = bpe_entry + BYTES_PER_NODE * sum(G.n_nodes) / n_entries
         layer_frac = bpe * (value / world) / HBM_PEAK
         roof = None
         if prof_name and prof_name in timed:
@@ -348,7 +352,8 @@ def main():
         line = {
             'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': value, 'unit': 'entries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32' if args.storage == 'f32' else 'bf16 storage / f32 accumulate', 'data': 'synthetic',
             'config': {'workload': f'S1/C1: {n_graphs} BA(64,5) graphs per GPU = {n_entries} entries '
                                    f'({n_offdiag} off-diagonal), KernelSelfAttn(2,2,32,32,32,4) generalized FAVOR+ '
                                    f'(d=8,m=16), fwd + sum().backward()',
@@ -358,6 +363,7 @@ def main():
                                        '/ 8 TB/s, GEMM time included in the denominator'},
             'roofline': roof,
             'k1_plan_build_ms': round(k1_ms, 3),
+            'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
             'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
         }
         if args.no_cpu_baseline or world > 1:

@@ -68,7 +68,8 @@ class Attn22Args(ctypes.Structure):
                  ('datt', _P), ('ld_datt', _L), ('dout', _P), ('ld_dout', _L),
                  ('dh1', _P), ('ld_dh1', _L), ('dh2', _P), ('ld_dh2', _L), ('dv', _P), ('ld_dv', _L),
                  ('ck', _P), ('dkvg', _P),
-                 ('kvn', _P), ('dkvn', _P), ('nd0', _P), ('dd0', _P), ('diag_w', ctypes.c_float)])
+                 ('kvn', _P), ('dkvn', _P), ('nd0', _P), ('dd0', _P), ('diag_w', ctypes.c_float), ('storage', ctypes.c_int32)])
+STORAGE_F32, STORAGE_BF16 = 0, 1
 
 
 # phases of hotk_attn22_phase (include/hotk.h)
@@ -81,6 +82,9 @@ _SIGNATURES.update({
     'hotk_attn22_backward': [ctypes.POINTER(Attn22Args), _P, _S, _P],
     'hotk_attn22_phase': [ctypes.POINTER(Attn22Args), c_int, _P, _S, _P],
     'hotk_attn22_forward_static': [ctypes.POINTER(Attn22Args), _P],
+    'hotk_linear22_entry_fwd_bf16': [_P, _L, _P, _L, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
+    'hotk_assemble22_bf16': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
+    'hotk_seg_sum_rows_bf16': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],
 })
 EXPORTS = sorted(list(_SIGNATURES) + ['hotk_strerror', 'hotk_version'])
 

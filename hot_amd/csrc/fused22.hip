@@ -30,8 +30,41 @@ constexpr int KVG_C = 25;                       // per-graph sums in memory: [B]
 constexpr float PHI_EPS = 1e-3f;
 
 using A = hotk_attn22_args;
+// typed views of the wide tensors of an argument block
+template <class ST>
+struct SV {
+  const ST *h2, *v, *datt;
+  ST *att, *dh2, *dv, *ck;
+  __device__ __forceinline__ explicit SV(const A& a)
+      : h2((const ST*)a.h2), v((const ST*)a.v), datt((const ST*)a.datt), att((ST*)a.att), dh2((ST*)a.dh2), dv((ST*)a.dv),
+        ck((ST*)a.ck) {}
+};
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ---- storage type ST of the wide entry-level tensors (h2, v, att and the gradients datt, dh2, dv, ck): float, or bf16 with
+// all arithmetic and every sum in fp32 (a->storage; BASELINE north_star: bf16 mode held to 2e-2).  Node-level tensors
+// (h1, phik, the key-value sums and their gradients) are always fp32.
+typedef __bf16 bf16;
+__device__ __forceinline__ float ldS(const float* p) { return *p; }
+__device__ __forceinline__ float ldS(const bf16* p) { return (float)*p; }
+__device__ __forceinline__ void stS(float* p, float v) { *p = v; }
+__device__ __forceinline__ void stS(bf16* p, float v) { *p = (bf16)v; }
+__device__ __forceinline__ float4 ld4(const bf16* p) {   // 4 consecutive elements (8-byte aligned)
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                     __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bf16* p, const float4& v) {
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f2v __attribute__((ext_vector_type(2)));
+  const bf16x2 a = __builtin_convertvector((f2v){v.x, v.y}, bf16x2), b = __builtin_convertvector((f2v){v.z, v.w}, bf16x2);
+  uint2 u;
+  u.x = __builtin_bit_cast(uint32_t, a);
+  u.y = __builtin_bit_cast(uint32_t, b);
+  *reinterpret_cast<uint2*>(p) = u;
+}
 
 // ---- 16-lane (one DPP row = one head) data movement on the VALU ---------------------------------------------
 // DPP controls: quad_perm [1,0,3,2] = 0xB1, quad_perm [2,3,0,1] = 0x4E, row_mirror = 0x140, row_half_mirror = 0x141,
@@ -209,8 +242,9 @@ __device__ __forceinline__ void kv_to_rot(const Lane& L, float* kvbuf, const flo
 
 // O = phi(q).KV / guard(phi(q).ks) for one slot (C layout: lanes x < 8 hold the 8 outputs of head h, lanes x >= 8 the
 // normaliser); writes 32 floats at out
+template <class OT>
 __device__ __forceinline__ void apply_fwd(const Lane& L, const float (&q)[DH], const float (&rot)[NM],
-                                          float* __restrict__ out) {
+                                          OT* __restrict__ out) {
   const float phi = phi_of(pre_x(L, q));
   const float num = rot_dot(phi, rot);
   // The reference replaces a zero normaliser by 1e-5 (kernelattncoef.py:68-71).  phi > 0 and the key sums are >= 0,
@@ -218,12 +252,13 @@ __device__ __forceinline__ void apply_fwd(const Lane& L, const float (&q)[DH], c
   // below gives the same quotient (0) with one instruction instead of a compare and a select.
   const float den = fmaxf(ror<8>(num), 1e-30f);
   const float o = num * __builtin_amdgcn_rcpf(den);
-  if (L.x < NC) out[L.h * NC + L.x] = o;
+  if (L.x < NC) stS(out + L.h * NC + L.x, o);
 }
 
 // backward of apply_fwd: writes d(raw q) (32 floats at dq) and accumulates dkv (F layout)
+template <class OT>
 __device__ __forceinline__ void apply_bwd(const LaneB& L, const float (&q)[DH], const float (&kv)[NC + 1],
-                                          const float (&g)[NC], float* __restrict__ dq, float (&dkv)[NC + 1]) {
+                                          const float (&g)[NC], OT* __restrict__ dq, float (&dkv)[NC + 1]) {
   const float pre = pre_x(L, q);
   const float phi = phi_of(pre);
   float s = kv[0] * g[0];
@@ -242,55 +277,59 @@ __device__ __forceinline__ void apply_bwd(const LaneB& L, const float (&q)[DH], 
   dkv[NC] = fmaf(phi, dden, dkv[NC]);
   const float dpre = pre > 0.f ? dphi : 0.f;
   const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) dq[L.h * DH + L.x] = d;
+  if (L.x < DH) stS(dq + L.h * DH + L.x, d);
 }
 
 // backward of one KV accumulation term: dV (32 floats at dv, may be null; drot = C layout of dKV with DUP) and
 // d(raw key) (32 floats at dk)
+template <class VT, class KT>
 __device__ __forceinline__ void kv_bwd(const LaneB& L, const float (&k)[DH], const float (&val)[NC],
-                                       const float (&dkv)[NC + 1], const float (&drot)[NM], float* __restrict__ dv,
-                                       float* __restrict__ dk) {
+                                       const float (&dkv)[NC + 1], const float (&drot)[NM], VT* __restrict__ dv,
+                                       KT* __restrict__ dk) {
   const float pre = pre_x(L, k);
   const float phi = phi_of(pre);
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
   const float dvv = rot_dot(phi, drot);
-  if (dv && L.x < NC) dv[L.h * NC + L.x] = dvv;
+  if (dv && L.x < NC) stS(dv + L.h * NC + L.x, dvv);
   const float dpre = pre > 0.f ? dphi : 0.f;
   const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) dk[L.h * DH + L.x] = d;
+  if (L.x < DH) stS(dk + L.h * DH + L.x, d);
 }
 
 // the same for a key whose feature phi comes from the per-node table (pre > 0  <=>  phi > eps)
+template <class VT, class KT>
 __device__ __forceinline__ void kv_bwd_phi(const LaneB& L, float phi, const float (&val)[NC], const float (&dkv)[NC + 1],
-                                           const float (&drot)[NM], float* __restrict__ dv, float* __restrict__ dk) {
+                                           const float (&drot)[NM], VT* __restrict__ dv, KT* __restrict__ dk) {
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
   const float dvv = rot_dot(phi, drot);
-  if (dv && L.x < NC) dv[L.h * NC + L.x] = dvv;
+  if (dv && L.x < NC) stS(dv + L.h * NC + L.x, dvv);
   const float dpre = phi > PHI_EPS ? dphi : 0.f;
   const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) dk[L.h * DH + L.x] = d;
+  if (L.x < DH) stS(dk + L.h * DH + L.x, d);
 }
 
 // the same for an entry that enters the column sum with weight w (split-phase mode: the replicated diagonal entry)
+template <class VT, class KT>
 __device__ __forceinline__ void kv_bwd_phi_w(const LaneB& L, float phi, float w, const float (&val)[NC],
-                                             const float (&dkv)[NC + 1], const float (&drot)[NM], float* __restrict__ dv,
-                                             float* __restrict__ dk) {
+                                             const float (&dkv)[NC + 1], const float (&drot)[NM], VT* __restrict__ dv,
+                                             KT* __restrict__ dk) {
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
   const float dvv = rot_dot(phi * w, drot);
-  if (dv && L.x < NC) dv[L.h * NC + L.x] = dvv;
+  if (dv && L.x < NC) stS(dv + L.h * NC + L.x, dvv);
   const float dpre = phi > PHI_EPS ? dphi * w : 0.f;
   const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) dk[L.h * DH + L.x] = d;
+  if (L.x < DH) stS(dk + L.h * DH + L.x, d);
 }
 
-__device__ __forceinline__ void zero_slots(const Lane& L, float* __restrict__ p, int nslots) {
-  for (int i = L.lane; i < nslots * SLOT; i += 64) p[i] = 0.f;
+template <class OT>
+__device__ __forceinline__ void zero_slots(const Lane& L, OT* __restrict__ p, int nslots) {
+  for (int i = L.lane; i < nslots * SLOT; i += 64) stS(p + i, 0.f);
 }
 
 // Software pipeline over `cnt` items, DEPTH 4: the NR coalesced row loads of items k+1..k+3 are in flight while
@@ -425,22 +464,23 @@ __device__ __forceinline__ void chunk_rows(const A& a, int64_t w, int cpg, int r
 
 // rows [ra, rb) of graph b, all diagonal (DIAG) or all off-diagonal.  Diagonal rows take phi(key) from the per-node
 // table (slots 6, 7), off-diagonal rows compute it from the raw entry-level key.
-template <bool DIAG>
+template <class ST, bool DIAG>
 __device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* stage, int64_t b, int64_t ra, int64_t rb,
                                               float (&kv)[4][NC + 1]) {
   const bool lo = L.lane < 32;
+  const SV<ST> S(a);
   auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
-    const float* vr = a.v + row * a.ld_v;
+    const ST* vr = S.v + row * a.ld_v;
     if (DIAG) {
       const int64_t n = b * a.Nmax + (row - b * a.Emax);
       r[0] = a.phik[n * a.ld_phik + 6 * 64 + L.lane];
       r[1] = a.phik[n * a.ld_phik + 7 * 64 + L.lane];
-      r[2] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];          // slot 6 | slot 8
+      r[2] = ldS(vr + (lo ? 6 * SLOT : 7 * SLOT) + L.lane);          // slot 6 | slot 8
     } else {
-      r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+      r[0] = ldS(S.h2 + row * a.ld_h2 + K2 * SLOT + L.lane);
       r[1] = 0.f;
-      r[2] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];          // slot 7 | slot 9
+      r[2] = ldS(vr + (lo ? 7 * SLOT : 8 * SLOT) + L.lane);          // slot 7 | slot 9
     }
   };
   auto use = [&](int, const float (&r)[3]) __attribute__((always_inline)) {
@@ -464,6 +504,7 @@ __device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* 
   pipeline4<3>((int)(rb - ra), load, use);
 }
 
+template <class ST>
 __global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
@@ -476,8 +517,8 @@ __global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ d
     const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
     float kv[4][NC + 1];
     kv_zero<4>(kv);
-    graphsum_rows<true>(L, a, stage, b, r0, rm, kv);
-    graphsum_rows<false>(L, a, stage, b, rm, r1, kv);
+    graphsum_rows<ST, true>(L, a, stage, b, r0, rm, kv);
+    graphsum_rows<ST, false>(L, a, stage, b, rm, r1, kv);
 #pragma unroll
     for (int s = 0; s < 4; ++s) part_store(L, dst + ((int64_t)w * 4 + s) * (NC + 1) * 64, kv[s]);
   }
@@ -566,7 +607,7 @@ __device__ __forceinline__ ColBlock col_block(const Lane& L, const A& a, int32_t
 
 // three coalesced loads for entry e = (i, j) of a column segment: phi of key slots {2p, 2p+1} of node i (per-node table,
 // F layout: the lane's own feature, no staging) and the value slots {2p | 2p+1}, the transposed one read from row te
-template <int P>
+template <class ST, int P>
 __device__ __forceinline__ void load_kv3(const Lane& L, const A& a, int32_t e, int32_t i, int32_t te, float (&r)[3]) {
   const float* pk = a.phik + rowoff(i, a.ld_phik) + 2 * P * 64 + L.lane;
   r[0] = pk[0];
@@ -575,18 +616,18 @@ __device__ __forceinline__ void load_kv3(const Lane& L, const A& a, int32_t e, i
   const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
   // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time:
   // selecting on the loaded value here would make the prefetch synchronous
-  r[2] = a.v[rowoff(row < 0 ? e : row, a.ld_v) + 2 * P * SLOT + L.lane];
+  r[2] = ldS((const ST*)a.v + rowoff(row < 0 ? e : row, a.ld_v) + 2 * P * SLOT + L.lane);
 }
 
 // per_entry(e, te, phi0, phi1, w): the two value slices are staged at stage[0..32) and stage[32..64); w is the weight of
 // the entry in the column sums: 1, or a.diag_w for the diagonal entry in split-phase (edge-shard) mode (W)
-template <int P, bool W = false, class F>
+template <class ST, int P, bool W = false, class F>
 __device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float* stage, int32_t n, F per_entry) {
   const int32_t c0 = a.col_ptr[n], c1 = a.col_ptr[n + 1];
   for (int32_t base = c0; base < c1; base += 64) {
     const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
     const ColBlock cb = col_block(L, a, base, cnt);
-    auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) { load_kv3<P>(L, a, rl(cb.e, k), rl(cb.i, k), rl(cb.te, k), r); };
+    auto load = [&](int k, float (&r)[3]) __attribute__((always_inline)) { load_kv3<ST, P>(L, a, rl(cb.e, k), rl(cb.i, k), rl(cb.te, k), r); };
     auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
       const float rv[1] = {r[2]};
       stage_put<1>(L, stage, rv);
@@ -596,10 +637,10 @@ __device__ __forceinline__ void for_col_entries(const Lane& L, const A& a, float
   }
 }
 
-template <int P, bool W = false>
+template <class ST, int P, bool W = false>
 __device__ __forceinline__ void seg_accumulate(const Lane& L, const A& a, float* stage, int32_t n, float (&kv)[2][NC + 1]) {
   kv_zero<2>(kv);
-  for_col_entries<P, W>(L, a, stage, n, [&](int32_t, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
+  for_col_entries<ST, P, W>(L, a, stage, n, [&](int32_t, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
     float val[8];
     if (W) { phi0 *= w; phi1 *= w; }   // weights values and normaliser alike
     const float ts = te < 0 ? 0.f : 1.f;   // the transposed-value slot is slot 0 for P == 2, slot 1 otherwise
@@ -636,7 +677,7 @@ __global__ __launch_bounds__(TPB) void k_seg_kvsum(A a) {
   for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
     if (!a.nkind[n]) continue;
     float kv[2][NC + 1];
-    seg_accumulate<P, true>(L, a, stage, (int32_t)n, kv);
+    seg_accumulate<float, P, true>(L, a, stage, (int32_t)n, kv);
     part_store(L, kvn_slot<P>(a, n, 0), kv[0]);
     part_store(L, kvn_slot<P>(a, n, 1), kv[1]);
     if (P == 0) {
@@ -698,8 +739,9 @@ __global__ __launch_bounds__(TPB) void k_node_dd(A a) {
 
 // GT: also the per-graph terms and the zero fill (false: k_graph_apply_fwd_t does them)
 // LOADKV: the node's sums come from a.kvn (split-phase mode) instead of being accumulated here
-template <int P, bool GT = true, bool LOADKV = false>
+template <class ST, int P, bool GT = true, bool LOADKV = false>
 __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
+  const SV<ST> S(a);
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const Lane L = make_lane(a.proj);
@@ -714,7 +756,7 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
         kvg_load(L, kvn_slot<P>(a, n, 0), kv[0]);
         kvg_load(L, kvn_slot<P>(a, n, 1), kv[1]);
       } else {
-        seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+        seg_accumulate<ST, P>(L, a, stage, (int32_t)n, kv);
       }
       kv_to_rot<false>(L, kvbuf, kv[0], rot0);
       kv_to_rot<false>(L, kvbuf, kv[1], rot1);
@@ -723,7 +765,7 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
       // node queries: terms 1, 2 (column sums) and 7, 8 (graph sums) go to the node's diagonal row
       const int64_t b = n / a.Nmax;
       const float* q = a.h1 + n * a.ld_h1;
-      float* o = a.att + rowoff(a.diag_pos[n], a.ld_att);
+      ST* o = S.att + rowoff(a.diag_pos[n], a.ld_att);
       float r[2] = {q[L.lane], q[64 + L.lane]};
       stage_put<2>(L, stage, r);
       float x[8];
@@ -751,13 +793,13 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
         const int cnt = (c1 - base) < 64 ? (c1 - base) : 64;
         const ColBlock cb = col_block(L, a, base, cnt);
         auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
-          const float* q = a.h2 + rowoff(rl(cb.e, k), a.ld_h2);
-          r[0] = q[L.lane];               // query slots 0, 1
-          r[1] = q[4 * SLOT + L.lane];    // query slots 4, 5
+          const ST* q = S.h2 + rowoff(rl(cb.e, k), a.ld_h2);
+          r[0] = ldS(q + L.lane);               // query slots 0, 1
+          r[1] = ldS(q + 4 * SLOT + L.lane);    // query slots 4, 5
         };
         auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
           if (rl(cb.kd, k) != 2) return;
-          float* o = a.att + rowoff(rl(cb.e, k), a.ld_att);
+          ST* o = S.att + rowoff(rl(cb.e, k), a.ld_att);
           stage_put<2>(L, stage, r);
           float x[8];
           slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 2 * SLOT);
@@ -765,8 +807,8 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
           if (GT) {
             slice8(L, stage + 2 * SLOT, x); apply_fwd(L, x, g0, o + 8 * SLOT);
             slice8(L, stage + 3 * SLOT, x); apply_fwd(L, x, g1, o + 9 * SLOT);
-            o[L.lane] = 0.f;                 // terms 1, 2 live on the diagonal only
-            o[6 * SLOT + L.lane] = 0.f;      // terms 7, 8 too
+            stS(o + L.lane, 0.f);                 // terms 1, 2 live on the diagonal only
+            stS(o + 6 * SLOT + L.lane, 0.f);      // terms 7, 8 too
           }
         };
         pipeline4<2>(cnt, load, use);
@@ -779,12 +821,12 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
         const int32_t rec = L.lane < cnt ? a.row_rec[base + L.lane] : -1;
         auto load = [&](int k, float (&r)[1]) __attribute__((always_inline)) {
           const int32_t e = rl(rec, k);
-          r[0] = a.h2[rowoff(e < 0 ? ~e : e, a.ld_h2) + 2 * SLOT + L.lane];
+          r[0] = ldS(S.h2 + rowoff(e < 0 ? ~e : e, a.ld_h2) + 2 * SLOT + L.lane);
         };
         auto use = [&](int k, const float (&r)[1]) __attribute__((always_inline)) {
           const int32_t e = rl(rec, k);
           if (e < 0) return;
-          float* o = a.att + rowoff(e, a.ld_att);
+          ST* o = S.att + rowoff(e, a.ld_att);
           stage_put<1>(L, stage, r);
           float x[8];
           slice8(L, stage + 0 * SLOT, x); apply_fwd(L, x, rot0, o + 3 * SLOT);
@@ -800,9 +842,10 @@ __global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
 // per-graph terms (backward): (1) query side + dKVg partials, (2) key/value side
 // ------------------------------------------------------------------------------------------------
 // rows [ra, rb) of graph b, all diagonal or all off-diagonal, against the two per-graph sums kv0 / kv1 of that kind
-template <bool DIAG>
+template <class ST, bool DIAG>
 __device__ __forceinline__ void graph_apply_bwd_rows(const LaneB& L, const A& a, float* stage, int64_t b, int64_t ra,
                                                      int64_t rb, float* __restrict__ dst) {
+  const SV<ST> S(a);
   if (rb <= ra) {
     float z[NC + 1];
 #pragma unroll
@@ -817,32 +860,40 @@ __device__ __forceinline__ void graph_apply_bwd_rows(const LaneB& L, const A& a,
   kv_zero<2>(dkv);
   auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
-    const float* g = a.datt + row * a.ld_datt;
+    const ST* g = S.datt + row * a.ld_datt;
     if (DIAG) {
       const int64_t n = b * a.Nmax + (row - b * a.Emax);
       r[0] = a.h1[n * a.ld_h1 + 2 * SLOT + L.lane];     // node query slots 2, 3
-      r[1] = g[6 * SLOT + L.lane];                       // d term 7, 8
+      r[1] = ldS(g + 6 * SLOT + L.lane);                 // d term 7, 8
     } else {
-      r[0] = a.h2[row * a.ld_h2 + 4 * SLOT + L.lane];   // entry query slots 4, 5
-      r[1] = g[8 * SLOT + L.lane];                       // d term 9, 10
+      r[0] = ldS(S.h2 + row * a.ld_h2 + 4 * SLOT + L.lane);   // entry query slots 4, 5
+      r[1] = ldS(g + 8 * SLOT + L.lane);                       // d term 9, 10
     }
   };
   auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
     stage_put<2>(L, stage, r);
     float x[8], g[8];
-    float* dq = DIAG ? a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 2 * SLOT
-                     : a.dh2 + row * a.ld_dh2 + 4 * SLOT;
-    slice8(L, stage, x); slice8(L, stage + 64, g);
-    apply_bwd(L, x, kv[0], g, dq, dkv[0]);
-    slice8(L, stage + 32, x); slice8(L, stage + 96, g);
-    apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
+    if (DIAG) {
+      float* dq = a.dh1 + (b * a.Nmax + (row - b * a.Emax)) * a.ld_dh1 + 2 * SLOT;
+      slice8(L, stage, x); slice8(L, stage + 64, g);
+      apply_bwd(L, x, kv[0], g, dq, dkv[0]);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, g);
+      apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
+    } else {
+      ST* dq = S.dh2 + row * a.ld_dh2 + 4 * SLOT;
+      slice8(L, stage, x); slice8(L, stage + 64, g);
+      apply_bwd(L, x, kv[0], g, dq, dkv[0]);
+      slice8(L, stage + 32, x); slice8(L, stage + 96, g);
+      apply_bwd(L, x, kv[1], g, dq + SLOT, dkv[1]);
+    }
   };
   pipeline4<2>((int)(rb - ra), load, use);
   part_store(L, dst + (DIAG ? 0 : 2) * (NC + 1) * 64, dkv[0]);
   part_store(L, dst + (DIAG ? 1 : 3) * (NC + 1) * 64, dkv[1]);
 }
 
+template <class ST>
 __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
@@ -854,8 +905,8 @@ __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict_
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
     const int64_t rm = r1 < nodes_end ? r1 : (r0 > nodes_end ? r0 : nodes_end);
     float* d = dst + (int64_t)w * 4 * (NC + 1) * 64;
-    graph_apply_bwd_rows<true>(L, a, stage, b, r0, rm, d);
-    graph_apply_bwd_rows<false>(L, a, stage, b, rm, r1, d);
+    graph_apply_bwd_rows<ST, true>(L, a, stage, b, r0, rm, d);
+    graph_apply_bwd_rows<ST, false>(L, a, stage, b, rm, r1, d);
   }
 }
 
@@ -864,11 +915,12 @@ __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict_
 #define HOTK_GB_ROWS 64   /* rows per wave: the two d(KV) sums (50 registers) are loaded once per chunk; 16: 4.4 ms, 32: 3.8, 64: 3.6 */
 #endif
 constexpr int GB_ROWS = HOTK_GB_ROWS, GB_ROWS_SMALL = 16;   // SMALL: batches with too few 64-row chunks to fill the chip
-template <bool DIAG>
+template <class ST, bool DIAG>
 __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, float* stage, int64_t b, int64_t ra,
                                                   int64_t rb) {
   if (rb <= ra) return;
   const bool lo = L.lane < 32;
+  const SV<ST> S(a);
   float d0[NC + 1], d1[NC + 1], t0[NM], t1[NM];
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), d0);
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), d1);
@@ -876,23 +928,23 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
   kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), t1);
   auto load = [&](int k, float (&r)[4]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
-    const float* vr = a.v + row * a.ld_v;
+    const ST* vr = S.v + row * a.ld_v;
     if (DIAG) {
       const int64_t n = b * a.Nmax + (row - b * a.Emax);
       r[0] = a.phik[n * a.ld_phik + 6 * 64 + L.lane];
       r[3] = a.phik[n * a.ld_phik + 7 * 64 + L.lane];
-      r[1] = vr[(lo ? 6 * SLOT : 7 * SLOT) + L.lane];
+      r[1] = ldS(vr + (lo ? 6 * SLOT : 7 * SLOT) + L.lane);
     } else {
-      r[0] = a.h2[row * a.ld_h2 + K2 * SLOT + L.lane];
+      r[0] = ldS(S.h2 + row * a.ld_h2 + K2 * SLOT + L.lane);
       r[3] = 0.f;
-      r[1] = vr[(lo ? 7 * SLOT : 8 * SLOT) + L.lane];
+      r[1] = ldS(vr + (lo ? 7 * SLOT : 8 * SLOT) + L.lane);
     }
     r[2] = (a.dout && L.lane < a.D) ? a.dout[row * a.ld_dout + L.lane] : 0.f;
   };
   auto use = [&](int k, const float (&r)[4]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
-    float* dvr = a.dv + row * a.ld_dv;
-    float* dh2r = a.dh2 + row * a.ld_dh2;
+    ST* dvr = S.dv + row * a.ld_dv;
+    ST* dh2r = S.dh2 + row * a.ld_dh2;
     float x[8], val[8];
     if (DIAG) {
       const float rv[1] = {r[1]};
@@ -902,7 +954,7 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
       kv_bwd_phi(L, r[0], val, d0, t0, dvr + 6 * SLOT, dkn);
       slice8(L, stage + 32, val);
       kv_bwd_phi(L, r[3], val, d1, t1, dvr + 8 * SLOT, dkn + SLOT);
-      if (lo) { dvr[7 * SLOT + L.lane] = 0.f; dvr[9 * SLOT + L.lane] = 0.f; }
+      if (lo) { stS(dvr + 7 * SLOT + L.lane, 0.f); stS(dvr + 9 * SLOT + L.lane, 0.f); }
       zero_slots(L, dh2r, 8);   // entry-level queries / keys are masked on the diagonal
     } else {
       stage_put<2>(L, stage, reinterpret_cast<const float (&)[2]>(r));
@@ -910,18 +962,18 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
       kv_bwd(L, x, val, d0, t0, dvr + 7 * SLOT, dh2r + K2 * SLOT);
       slice8(L, stage + 32, x); slice8(L, stage + 96, val);
       kv_bwd(L, x, val, d1, t1, dvr + 9 * SLOT, dh2r + (K2 + 1) * SLOT);
-      if (lo) { dvr[6 * SLOT + L.lane] = 0.f; dvr[8 * SLOT + L.lane] = 0.f; }
+      if (lo) { stS(dvr + 6 * SLOT + L.lane, 0.f); stS(dvr + 8 * SLOT + L.lane, 0.f); }
     }
     // skip path: d h2[:, 8 slots:] = d out (zero when the caller routes that gradient elsewhere)
-    if (L.lane < a.D) dh2r[8 * SLOT + L.lane] = r[2];
-    for (int i = 64 + L.lane; i < a.D; i += 64) dh2r[8 * SLOT + i] = a.dout ? a.dout[row * a.ld_dout + i] : 0.f;
+    if (L.lane < a.D) stS(dh2r + 8 * SLOT + L.lane, r[2]);
+    for (int i = 64 + L.lane; i < a.D; i += 64) stS(dh2r + 8 * SLOT + i, a.dout ? a.dout[row * a.ld_dout + i] : 0.f);
   };
   pipeline4<4>((int)(rb - ra), load, use);
 }
 
 // wave per chunk of 16 consecutive rows of one kind of one graph; one instantiation per kind, so that only that kind's
 // two dKVg slots (F layout + rotated) are live
-template <bool DIAG, int ROWS = GB_ROWS>
+template <class ST, bool DIAG, int ROWS = GB_ROWS>
 __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
@@ -935,7 +987,7 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
     const int64_t lo = b * a.Emax + (DIAG ? 0 : nn), hi = b * a.Emax + (DIAG ? nn : (int64_t)a.n_entries[b]);
     const int64_t r0 = lo + k * ROWS;
     const int64_t r1 = r0 + ROWS < hi ? r0 + ROWS : hi;
-    graphsum_bwd_rows<DIAG>(L, a, stage, b, r0, r1);
+    graphsum_bwd_rows<ST, DIAG>(L, a, stage, b, r0, r1);
   }
 }
 
@@ -948,8 +1000,9 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
 // MODE 0: the whole backward of a (node, part).  Split-phase mode: MODE 1 = query side only (the node's sums come from
 // a.kvn, d(sums) go to a.dkvn for the caller to all-reduce), MODE 2 = key / value side only (d(sums) from a.dkvn),
 // MODE 3 = key / value side of part 0 (d(sums) rebuilt from the all-reduced [d num | d den] of the node queries)
-template <int P, int MODE = 0>
+template <class ST, int P, int MODE = 0>
 __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
+  const SV<ST> S(a);
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const LaneB L = make_lane_b(a.proj);
@@ -999,11 +1052,11 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
         kvg_load(L, kvn_slot<P>(a, n, 0), kv[0]);
         kvg_load(L, kvn_slot<P>(a, n, 1), kv[1]);
       } else {
-        seg_accumulate<P>(L, a, stage, (int32_t)n, kv);
+        seg_accumulate<ST, P>(L, a, stage, (int32_t)n, kv);
       }
       if (P == 0) {  // node queries (terms 1, 2)
         const int64_t dr = a.diag_pos[n];
-        float r[2] = {a.h1[n * a.ld_h1 + L.lane], a.datt[rowoff((int32_t)dr, a.ld_datt) + L.lane]};
+        float r[2] = {a.h1[n * a.ld_h1 + L.lane], ldS(S.datt + rowoff((int32_t)dr, a.ld_datt) + L.lane)};
         float* dq = a.dh1 + n * a.ld_dh1;
         stage_put<2>(L, stage, r);
         float x[8], g[8];
@@ -1016,12 +1069,12 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
           const ColBlock cb = col_block(L, a, base, cnt);
           auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
             const int64_t e = rl(cb.e, k);
-            r[0] = a.h2[rowoff((int32_t)e, a.ld_h2) + L.lane];                                      // query slots 0, 1
-            r[1] = a.datt[rowoff((int32_t)e, a.ld_datt) + (lo ? 2 * SLOT : 3 * SLOT) + L.lane];      // d term 3 | d term 5
+            r[0] = ldS(S.h2 + rowoff((int32_t)e, a.ld_h2) + L.lane);                                      // query slots 0, 1
+            r[1] = ldS(S.datt + rowoff((int32_t)e, a.ld_datt) + (lo ? 2 * SLOT : 3 * SLOT) + L.lane);      // d term 3 | d term 5
           };
           auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
             if (rl(cb.kd, k) != 2) return;
-            float* dq = a.dh2 + rowoff(rl(cb.e, k), a.ld_dh2);
+            ST* dq = S.dh2 + rowoff(rl(cb.e, k), a.ld_dh2);
             stage_put<2>(L, stage, r);
             float x[8], g[8];
             slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
@@ -1037,13 +1090,13 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
           auto load = [&](int k, float (&r)[2]) __attribute__((always_inline)) {
             const int32_t e_ = rl(rec, k);
             const int64_t e = e_ < 0 ? ~e_ : e_;
-            r[0] = a.h2[rowoff((int32_t)e, a.ld_h2) + 2 * SLOT + L.lane];                            // query slots 2, 3
-            r[1] = a.datt[rowoff((int32_t)e, a.ld_datt) + (lo ? 3 * SLOT : 4 * SLOT) + L.lane];      // d term 4 | d term 6
+            r[0] = ldS(S.h2 + rowoff((int32_t)e, a.ld_h2) + 2 * SLOT + L.lane);                            // query slots 2, 3
+            r[1] = ldS(S.datt + rowoff((int32_t)e, a.ld_datt) + (lo ? 3 * SLOT : 4 * SLOT) + L.lane);      // d term 4 | d term 6
           };
           auto use = [&](int k, const float (&r)[2]) __attribute__((always_inline)) {
             const int32_t e = rl(rec, k);
             if (e < 0) return;
-            float* dq = a.dh2 + rowoff(e, a.ld_dh2) + 2 * SLOT;
+            ST* dq = S.dh2 + rowoff(e, a.ld_dh2) + 2 * SLOT;
             stage_put<2>(L, stage, r);
             float x[8], g[8];
             slice8(L, stage + 0 * SLOT, x); slice8(L, stage + 2 * SLOT, g); apply_bwd(L, x, kv[0], g, dq, dkv[0]);
@@ -1063,13 +1116,13 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
     float drot0[NM], drot1[NM];
     kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
     kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
-    for_col_entries<P, (MODE >= 2)>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
-      float* dve = a.dv + rowoff(e, a.ld_dv);
-      float* dvt = te >= 0 ? a.dv + rowoff(te, a.ld_dv) : nullptr;
-      float* ck = a.ck + rowoff(e, 6 * SLOT) + 2 * P * SLOT;
+    for_col_entries<ST, P, (MODE >= 2)>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
+      ST* dve = S.dv + rowoff(e, a.ld_dv);
+      ST* dvt = te >= 0 ? S.dv + rowoff(te, a.ld_dv) : nullptr;
+      ST* ck = S.ck + rowoff(e, 6 * SLOT) + 2 * P * SLOT;
       constexpr int S0 = 2 * P, S1 = 2 * P + 1;
-      float* d0 = (P == 2) ? (dvt ? dvt + S0 * SLOT : nullptr) : dve + S0 * SLOT;
-      float* d1 = (P == 2) ? dve + S1 * SLOT : (dvt ? dvt + S1 * SLOT : nullptr);
+      ST* d0 = (P == 2) ? (dvt ? dvt + S0 * SLOT : nullptr) : dve + S0 * SLOT;
+      ST* d1 = (P == 2) ? dve + S1 * SLOT : (dvt ? dvt + S1 * SLOT : nullptr);
       float val[8];
       slice8(L, stage + 0 * SLOT, val);
       if (P == 2 && te < 0) {
@@ -1085,7 +1138,7 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
       }
       if (MODE >= 2) kv_bwd_phi_w(L, phi1, w, val, dkv[1], drot1, d1, ck + SLOT);
       else kv_bwd_phi(L, phi1, val, dkv[1], drot1, d1, ck + SLOT);
-      if (te < 0 && lo) dve[((P == 2) ? S0 : S1) * SLOT + L.lane] = 0.f;   // no transposed partner writes this slot
+      if (te < 0 && lo) stS(dve + ((P == 2) ? S0 : S1) * SLOT + L.lane, 0.f);   // no transposed partner writes this slot
     });
   }
 }
@@ -1131,7 +1184,7 @@ __device__ __forceinline__ f16v zero16() {
 
 // the two column sums of part P for node n in the T layout (register 4h + r: feature 4g + r of head h, channel on x):
 // kv0 with values on x < 8 / key sum on x >= 8, kv1 with values on x >= 8 / key sum on x < 8
-template <int P>
+template <class ST, int P>
 __device__ __forceinline__ void seg_accumulate_t(const LaneT& L, const A& a, int32_t n, f16v& kv0, f16v& kv1) {
   kv0 = zero16();
   kv1 = zero16();
@@ -1151,7 +1204,7 @@ __device__ __forceinline__ void seg_accumulate_t(const LaneT& L, const A& a, int
       r[1] = pk[64];
       const int32_t tr = te < 0 ? e : te;   // a missing transposed entry is masked at use time
       const int64_t o0 = rowoff(P == 2 ? tr : e, a.ld_v), o1 = rowoff(P == 2 ? e : tr, a.ld_v);
-      r[2] = a.v[(lo8 ? o0 : o1) + vcol];
+      r[2] = ldS((const ST*)a.v + (lo8 ? o0 : o1) + vcol);
     };
     auto use = [&](int k, const float (&r)[3]) __attribute__((always_inline)) {
       const bool ok = rl(cb.te, k) >= 0;
@@ -1193,7 +1246,8 @@ struct TileRaw { float4 r[4]; };
 struct TileQ { float2 a[NH], b[NH]; };
 
 // rows[r]: row of entry 4g + r; col: first of the 64 columns (two adjacent slots)
-__device__ __forceinline__ void tile_raw_load(const LaneT& L, const float* const (&rows)[4], int col, TileRaw& t) {
+template <class QT>
+__device__ __forceinline__ void tile_raw_load(const LaneT& L, const QT* const (&rows)[4], int col, TileRaw& t) {
 #pragma unroll
   for (int r = 0; r < 4; ++r) t.r[r] = ld4(rows[r] + col + 4 * L.x);
 }
@@ -1214,8 +1268,9 @@ __device__ __forceinline__ void tile_fragments(const LaneT& L, float* tile, cons
 // entry t = 4g + r; oa / ob: output columns of the two slots.  Straight-line code: every lane stores (positions
 // without an entry of their own repeat another entry of the segment, see tile_rows).  Two heads at a time: four
 // independent MFMA chains cover the 40-cycle dependent latency and the live set stays small.
+template <class OT>
 __device__ __forceinline__ void tile_apply_pair_fwd(const LaneT& L, float* tile, const TileQ& q, const f16v& kvA,
-                                                    const f16v& kvB, float* const (&orow)[4], int oa, int ob) {
+                                                    const f16v& kvB, OT* const (&orow)[4], int oa, int ob) {
   const bool lo8 = L.x < 8;
   const f4v eps4 = {PHI_EPS, PHI_EPS, PHI_EPS, PHI_EPS};
   const f4v z4 = {0.f, 0.f, 0.f, 0.f};
@@ -1256,15 +1311,16 @@ __device__ __forceinline__ void tile_apply_pair_fwd(const LaneT& L, float* tile,
   const int ocol = lo8 ? oa + 4 * L.x : ob + 4 * (L.x - 8);
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    *reinterpret_cast<float4*>(orow[r] + ocol) = *reinterpret_cast<const float4*>(tile + (4 * L.g + r) * TS + 4 * L.x);
+    st4(orow[r] + ocol, *reinterpret_cast<const float4*>(tile + (4 * L.g + r) * TS + 4 * L.x));
 }
 
 // zero `nf4` float4s (a multiple of 16) at column `col` of the four rows of this lane group (16 lanes per row)
-__device__ __forceinline__ void tile_zero_rows(const LaneT& L, float* const (&orow)[4], int col, int nf4) {
+template <class OT>
+__device__ __forceinline__ void tile_zero_rows(const LaneT& L, OT* const (&orow)[4], int col, int nf4) {
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int r = 0; r < 4; ++r)
-    for (int j = L.x; j < nf4; j += 16) reinterpret_cast<float4*>(orow[r] + col)[j] = z;
+    for (int j = L.x; j < nf4; j += 16) st4(orow[r] + col + 4 * j, z);
 }
 
 // Entry rows of one 16-position tile [t0, t0 + 16) of a non-empty segment [.., c1) (column segment for P == 1, row
@@ -1298,8 +1354,9 @@ __device__ __forceinline__ void tile_rows(const LaneT& L, const A& a, int32_t t0
   for (int r = 0; r < 4; ++r) eb[r] = (rb[r] >= 0 && t0 + 4 * L.g + r <= last) ? rb[r] : sub;
 }
 
-template <int P>
+template <class ST, int P>
 __global__ __launch_bounds__(TPB, 4) void k_segt_fwd(A a) {
+  const SV<ST> S(a);
   __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
   float* tile = tile_all[threadIdx.x >> 6];
   const LaneT L = make_lane_t(a.proj);
@@ -1319,24 +1376,24 @@ __global__ __launch_bounds__(TPB, 4) void k_segt_fwd(A a) {
     }
     TileRaw raw;
     {
-      const float* rows[4];
+      const ST* rows[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) rows[r] = a.h2 + rowoff(eb[r], a.ld_h2);
+      for (int r = 0; r < 4; ++r) rows[r] = S.h2 + rowoff(eb[r], a.ld_h2);
       tile_raw_load(L, rows, QC, raw);   // in flight during the accumulation
     }
     f16v kv0, kv1;
-    seg_accumulate_t<P>(L, a, (int32_t)n, kv0, kv1);
+    seg_accumulate_t<ST, P>(L, a, (int32_t)n, kv0, kv1);
     for (int32_t t0 = c0; t0 < c1; t0 += 16) {
       if (t0 != c0) {
         tile_rows<P, false>(L, a, t0, c1, sub, eb);
-        const float* rows[4];
+        const ST* rows[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rows[r] = a.h2 + rowoff(eb[r], a.ld_h2);
+        for (int r = 0; r < 4; ++r) rows[r] = S.h2 + rowoff(eb[r], a.ld_h2);
         tile_raw_load(L, rows, QC, raw);
       }
-      float* orow[4];
+      ST* orow[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) orow[r] = a.att + rowoff(eb[r], a.ld_att);
+      for (int r = 0; r < 4; ++r) orow[r] = S.att + rowoff(eb[r], a.ld_att);
       TileQ q;
       tile_fragments(L, tile, raw, q);
       tile_apply_pair_fwd(L, tile, q, kv0, kv1, orow, OA, OB);
@@ -1352,7 +1409,9 @@ constexpr int GA_TILES = 8;   // 16-row tiles per wave
 #ifndef HOTK_GA_WAVES
 #define HOTK_GA_WAVES 4
 #endif
+template <class ST>
 __global__ __launch_bounds__(TPB, HOTK_GA_WAVES) void k_graph_apply_fwd_t(A a) {
+  const SV<ST> S(a);
   __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
   float* tile = tile_all[threadIdx.x >> 6];
   const LaneT L = make_lane_t(a.proj);
@@ -1369,29 +1428,37 @@ __global__ __launch_bounds__(TPB, HOTK_GA_WAVES) void k_graph_apply_fwd_t(A a) {
     const int32_t r1 = r0 + 16 * GA_TILES < hi ? r0 + 16 * GA_TILES : hi;
     const int32_t last = r1 - 1;   // rows past the end repeat the last row
     const int64_t ebase = b * a.Emax, nbase = b * a.Nmax;
-    const float* qbase = diag ? a.h1 + nbase * a.ld_h1 : a.h2 + ebase * a.ld_h2;
-    const int64_t ldq = diag ? a.ld_h1 : a.ld_h2;
+    // diagonal rows take their queries from the node table h1 (always fp32), off-diagonal rows from h2 (storage type)
+    const float* qnode = a.h1 + nbase * a.ld_h1;
+    const ST* qentry = S.h2 + ebase * a.ld_h2;
     const int qc = diag ? 2 * SLOT : 4 * SLOT;
     const int oa = diag ? 6 * SLOT : 8 * SLOT, ob = oa + SLOT;
     auto load_tile = [&](int32_t t0, TileRaw& raw) __attribute__((always_inline)) {
-      const float* rows[4];
+      int32_t tb[4];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int32_t tb = t0 + 4 * L.g + r < last ? t0 + 4 * L.g + r : last;
-        rows[r] = qbase + (diag ? tb : tb) * ldq;
+      for (int r = 0; r < 4; ++r) tb[r] = t0 + 4 * L.g + r < last ? t0 + 4 * L.g + r : last;
+      if (diag) {
+        const float* rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[r] = qnode + tb[r] * a.ld_h1;
+        tile_raw_load(L, rows, qc, raw);
+      } else {
+        const ST* rows[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rows[r] = qentry + tb[r] * a.ld_h2;
+        tile_raw_load(L, rows, qc, raw);
       }
-      tile_raw_load(L, rows, qc, raw);
     };
     TileRaw raw;
     load_tile(r0, raw);
     const f16v g0 = kvg_load_t<false>(L, kvg_slot(a.kvg, b, diag ? 0 : 2));
     const f16v g1 = kvg_load_t<true>(L, kvg_slot(a.kvg, b, diag ? 1 : 3));
     for (int32_t t0 = r0; t0 < r1; t0 += 16) {
-      float* orow[4];
+      ST* orow[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int32_t tb = t0 + 4 * L.g + r < last ? t0 + 4 * L.g + r : last;
-        orow[r] = a.att + (ebase + tb) * a.ld_att;
+        orow[r] = S.att + (ebase + tb) * a.ld_att;
       }
       TileQ q;
       tile_fragments(L, tile, raw, q);
@@ -1411,6 +1478,7 @@ __global__ __launch_bounds__(TPB, HOTK_GA_WAVES) void k_graph_apply_fwd_t(A a) {
 int check_args(const A* a) {
   if (!a) return HOTK_EINVAL;
   if (a->H != NH || a->m != NM || a->d_head != DH || a->c != NC) return HOTK_EUNSUPPORTED;
+  if (a->storage != HOTK_STORAGE_F32 && a->storage != HOTK_STORAGE_BF16) return HOTK_EINVAL;
   if (a->B < 0 || a->Emax < 0 || a->Nmax < 0 || a->R != a->B * a->Emax || a->Nn != a->B * a->Nmax) return HOTK_EINVAL;
   if (!a->phik || a->ld_phik < 8 * 64) return HOTK_EINVAL;
   if (!a->h1 || !a->h2 || !a->v || !a->proj || !a->kind || !a->nkind || !a->rown || !a->coln || !a->tpos ||
@@ -1449,15 +1517,16 @@ void chunking(int64_t B, int64_t Emax, int* cpg, int* rows) {
   *rows = (int)((Emax + c - 1) / c);
 }
 
+template <class ST>
 void launch_graphsum_bwd(hipStream_t st, const A* a) {
   if (a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS) < 2048) {
     constexpr int RW = GB_ROWS_SMALL;
-    hipLaunchKernelGGL((k_graphsum_bwd<true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_graphsum_bwd<false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
   } else {
     constexpr int RW = GB_ROWS;
-    hipLaunchKernelGGL((k_graphsum_bwd<true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_graphsum_bwd<false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
   }
 }
 
@@ -1481,26 +1550,30 @@ extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* byte
 namespace {
 // forward launches; `part` holds the per-chunk partial graph sums (hotk_attn22_workspace_bytes): every chunk of it is
 // written by k_graphsum_fwd before k_graph_reduce reads it, so it needs no clearing
-int attn22_forward_launch(const A* a, float* part, hipStream_t st) {
+template <class ST>
+int attn22_forward_launch_t(const A* a, float* part, hipStream_t st) {
   int cpg, rows;
   chunking(a->B, a->Emax, &cpg, &rows);
   unsigned g1 = hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP);
-  hipLaunchKernelGGL(k_graphsum_fwd, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
+  hipLaunchKernelGGL(k_graphsum_fwd<ST>, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
   launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
   if (core_valu()) {
-    hipLaunchKernelGGL((k_seg_fwd<1, true>), gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_seg_fwd<2, true>), gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_seg_fwd<0, true>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<ST, 1, true>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<ST, 2, true>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<ST, 0, true>), gseg, dim3(TPB), 0, st, *a);
   } else {
     const int64_t per = 16 * GA_TILES;
     const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
-    hipLaunchKernelGGL(k_graph_apply_fwd_t, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL(k_segt_fwd<1>, gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL(k_segt_fwd<2>, gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_seg_fwd<0, false>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL(k_graph_apply_fwd_t<ST>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_segt_fwd<ST, 1>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_segt_fwd<ST, 2>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<ST, 0, false>), gseg, dim3(TPB), 0, st, *a);
   }
   return hotk_launch_status();
+}
+int attn22_forward_launch(const A* a, float* part, hipStream_t st) {
+  return a->storage == HOTK_STORAGE_BF16 ? attn22_forward_launch_t<bf16>(a, part, st) : attn22_forward_launch_t<float>(a, part, st);
 }
 }  // namespace
 
@@ -1555,6 +1628,20 @@ extern "C" int hotk_attn22_forward_static(const hotk_attn22_args* a, void* strea
   return attn22_forward_launch(a, part, (hipStream_t)stream);
 }
 
+namespace {
+template <class ST>
+int attn22_backward_launch_t(const A* a, float* part, int cpg, int rows, hipStream_t st) {
+  hipLaunchKernelGGL(k_graph_apply_bwd<ST>, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
+  launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
+  launch_graphsum_bwd<ST>(st, a);
+  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
+  hipLaunchKernelGGL((k_seg_bwd<ST, 1>), gseg, dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL((k_seg_bwd<ST, 2>), gseg, dim3(TPB), 0, st, *a);
+  hipLaunchKernelGGL((k_seg_bwd<ST, 0>), gseg, dim3(TPB), 0, st, *a);
+  return hotk_launch_status();
+}
+}  // namespace
+
 extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, size_t ws_bytes, void* stream) {
   int rc = check_args(a);
   if (rc) return rc;
@@ -1571,14 +1658,8 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
   float* part = (float*)workspace;
-  hipLaunchKernelGGL(k_graph_apply_bwd, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
-  launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
-  launch_graphsum_bwd(st, a);
-  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
-  hipLaunchKernelGGL(k_seg_bwd<1>, gseg, dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_bwd<2>, gseg, dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL(k_seg_bwd<0>, gseg, dim3(TPB), 0, st, *a);
-  return hotk_launch_status();
+  return a->storage == HOTK_STORAGE_BF16 ? attn22_backward_launch_t<bf16>(a, part, cpg, rows, st)
+                                        : attn22_backward_launch_t<float>(a, part, cpg, rows, st);
 }
 
 // The core in phases for one graph sharded by entries (include/hotk.h): the caller all-reduces kvg / kvn after the
@@ -1589,6 +1670,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   int rc = check_args(a);
   if (rc) return rc;
   HOTK_CHECK_ARG(phase >= HOTK_ATTN22_FWD_GRAPHSUM && phase <= HOTK_ATTN22_BWD_KEYVAL);
+  if (a->storage != HOTK_STORAGE_F32) return HOTK_EUNSUPPORTED;   // the sums exchanged between the phases are fp32 tables
   HOTK_CHECK_ARG(a->kvg && a->kvn && a->nd0 && hotk_aligned16(a->kvn) && a->diag_w > 0.f);
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -1602,7 +1684,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   switch (phase) {
     case HOTK_ATTN22_FWD_GRAPHSUM:
       if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-      hipLaunchKernelGGL(k_graphsum_fwd, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
+      hipLaunchKernelGGL(k_graphsum_fwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
       launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
       break;
     case HOTK_ATTN22_FWD_NODESUM:
@@ -1614,9 +1696,9 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       HOTK_CHECK_ARG(a->att && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
       const int64_t per = 16 * GA_TILES;
       const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
-      hipLaunchKernelGGL(k_graph_apply_fwd_t, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL((k_seg_fwd<1, false, true>), gseg, dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL((k_seg_fwd<2, false, true>), gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL(k_graph_apply_fwd_t<float>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gseg, dim3(TPB), 0, st, *a);
       hipLaunchKernelGGL(k_node_apply_nd, gseg, dim3(TPB), 0, st, *a);
       break;
     }
@@ -1629,16 +1711,16 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       HOTK_CHECK_ARG(!a->dout || a->ld_dout >= a->D);
       if (phase == HOTK_ATTN22_BWD_QUERY) {
         if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-        hipLaunchKernelGGL(k_graph_apply_bwd, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
+        hipLaunchKernelGGL(k_graph_apply_bwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
         launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
-        hipLaunchKernelGGL((k_seg_bwd<1, 1>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<2, 1>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<float, 1, 1>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<float, 2, 1>), gseg, dim3(TPB), 0, st, *a);
         hipLaunchKernelGGL(k_node_dd, gseg, dim3(TPB), 0, st, *a);
       } else {
-        launch_graphsum_bwd(st, a);
-        hipLaunchKernelGGL((k_seg_bwd<1, 2>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<2, 2>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<0, 3>), gseg, dim3(TPB), 0, st, *a);
+        launch_graphsum_bwd<float>(st, a);
+        hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gseg, dim3(TPB), 0, st, *a);
       }
       break;
   }

@@ -64,6 +64,7 @@ struct Epi {
   const int32_t* coln;
   const float* b_off;     // MODE 1: [C] or null
   const float* b_diag;
+  int out_bf16;           // Y is a bf16 tensor (ldy in bf16 elements): the fp32 result is rounded once at the store
 };
 
 // The epilogue runs on a row-major image of the 32 x 32 result tile: the accumulators (lane pair = one row, 16 bytes
@@ -292,7 +293,15 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
             }
             if (has_res) { v.x += cur.u[i].x; v.y += cur.u[i].y; v.z += cur.u[i].z; v.w += cur.u[i].w; }
           }
-          if (MODE == 1 ? kd >= 0 : kd != 0) {
+          if ((MODE == 1 ? kd >= 0 : kd != 0) && ep.out_bf16) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            typedef float f2v __attribute__((ext_vector_type(2)));
+            const bf16x2 lo2 = __builtin_convertvector((f2v){v.x, v.y}, bf16x2), hi2 = __builtin_convertvector((f2v){v.z, v.w}, bf16x2);
+            uint2 u;
+            u.x = __builtin_bit_cast(uint32_t, lo2);
+            u.y = __builtin_bit_cast(uint32_t, hi2);
+            *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(Y) + (row0 + 8 * i + er) * ldy + col0 + ec) = u;
+          } else if (MODE == 1 ? kd >= 0 : kd != 0) {
             float4* yp = reinterpret_cast<float4*>(Y + (row0 + 8 * i + er) * ldy + col0 + ec);
 #ifdef HOTK_GEMM_NT   /* nontemporal result stores: measured within noise at 10 M rows (entry GEMM 5.07 vs 4.88 ms, the others +-1 %) */
             typedef float f4 __attribute__((ext_vector_type(4)));
@@ -391,10 +400,30 @@ extern "C" int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, 
   return dispatch<0>(A, lda, W, K, C, Y, ldy, R, ep, (hipStream_t)stream);
 }
 
+namespace {
+int entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn, int64_t ld_yn,
+              const uint8_t* kind, const int32_t* rown, const int32_t* coln, const float* b_off, const float* b_diag,
+              float* Y, int64_t ldy, int64_t R, int64_t Nn, int out_bf16, void* stream);
+}
+
 extern "C" int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
                                        int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
                                        const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R,
                                        int64_t Nn, void* stream) {
+  return entry_fwd(x2, ld_x2, W, K, C, yn, ld_yn, kind, rown, coln, b_off, b_diag, Y, ldy, R, Nn, 0, stream);
+}
+
+extern "C" int hotk_linear22_entry_fwd_bf16(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C,
+                                            const float* yn, int64_t ld_yn, const uint8_t* kind, const int32_t* rown,
+                                            const int32_t* coln, const float* b_off, const float* b_diag, void* Y,
+                                            int64_t ldy, int64_t R, int64_t Nn, void* stream) {
+  return entry_fwd(x2, ld_x2, W, K, C, yn, ld_yn, kind, rown, coln, b_off, b_diag, (float*)Y, ldy, R, Nn, 1, stream);
+}
+
+namespace {
+int entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn, int64_t ld_yn,
+              const uint8_t* kind, const int32_t* rown, const int32_t* coln, const float* b_off, const float* b_diag,
+              float* Y, int64_t ldy, int64_t R, int64_t Nn, int out_bf16, void* stream) {
   HOTK_CHECK_ARG(R >= 0 && K > 0 && C > 0 && ld_x2 >= K && ldy >= C && ld_yn >= 3 * C);
   if (!shape_ok(K, C)) return HOTK_EUNSUPPORTED;
   if (R == 0) return HOTK_OK;
@@ -405,5 +434,7 @@ extern "C" int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const flo
   if (Nn < 0 || Nn * ld_yn >= ((int64_t)1 << 32)) return HOTK_EUNSUPPORTED;
   Epi ep{};
   ep.yn = yn; ep.ld_yn = ld_yn; ep.kind = kind; ep.rown = rown; ep.coln = coln; ep.b_off = b_off; ep.b_diag = b_diag;
+  ep.out_bf16 = out_bf16;
   return dispatch<1>(x2, ld_x2, W, K, C, Y, ldy, R, ep, (hipStream_t)stream);
 }
+}  // namespace

@@ -53,6 +53,15 @@ class KernelSelfAttn(nn.Module):
         self.dropout = nn.Dropout(p=dropout, inplace=True)
         self.mu_dropout = MuDropout(p=drop_mu)
         self.use_fused = True   # fused HIP attention core when the shape allows it (see _fused_ok)
+        self.storage = 'f32'    # 'bf16': wide intermediates of the fused 2->2 path in bf16 (set_storage)
+
+    def set_storage(self, storage):
+        """'f32' (the reference's precision) or 'bf16': h2 = fc_2(G), v = fc_v(values), the attention terms and their
+        gradients are stored in bf16 with fp32 accumulation (ops.AttnLayer22BF16; fused 2->2 shape only -- other layers
+        ignore the switch).  Parameters, layer inputs / outputs and node-level tensors stay fp32."""
+        assert storage in ('f32', 'bf16')
+        self.storage = storage
+        return self
 
     def reset_vo_parameters(self):
         nn.init.xavier_normal_(self.fc_v.weight)
@@ -116,6 +125,14 @@ class KernelSelfAttn(nn.Module):
 
     def _2_to_2(self, G: B):
         h_1 = self.fc_1(G)                      # [B, N, 12 dqk]: 4 query slots, 8 key slots
+        if self.storage == 'bf16' and self._fused_ok() and getattr(G.plan, 'shard', None) is None:
+            drop_p = self.dropout.p if self.training else 0.
+            mu_p = self.mu_dropout.p if self.training else 0.
+            fb = self.fc_2.bias.bias if hasattr(self.fc_2, 'bias') else (None, None)
+            out = ops.AttnLayer22BF16.apply(G.values, h_1.values, self.fc_2.weight.weight, fb[0], fb[1],
+                                            self.fc_v.weight, self.fc_v.bias, self.fc_o.weight, self.fc_o.bias,
+                                            self.feature_map.feature_map.projection_matrix, G.plan, drop_p, mu_p)
+            return batch_like(G, out, skip_masking=True)
         h_2 = self.fc_2(G)                      # [B, |E|, 8 dqk + D]: 6 query slots, 2 key slots, skip path
         if self._fused_ok():   # (edge-shard mode: ops.AttnCore22 runs the core in phases with all-reduces in between)
             # padding rows are ignored by the kernels: no masking pass

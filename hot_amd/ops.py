@@ -680,13 +680,13 @@ def wgrad(A, B):
     (torch.bmm -> rocBLAS/hipBLASLt batched GEMM) whose partial products are summed: split-K over 256 CUs."""
     R = A.size(0)
     if R < (1 << 16):
-        return A.t() @ B
+        return (A.t() @ B).float()
     S = 256
     rs = R // S
     main = rs * S
-    out = torch.bmm(A[:main].view(S, rs, A.size(1)).transpose(1, 2), B[:main].view(S, rs, B.size(1))).sum(0)
+    out = torch.bmm(A[:main].view(S, rs, A.size(1)).transpose(1, 2), B[:main].view(S, rs, B.size(1))).float().sum(0)
     if main < R:
-        out = out + A[main:].t() @ B[main:]
+        out = out + (A[main:].t() @ B[main:]).float()
     return out
 
 
@@ -905,6 +905,154 @@ class AttnCore22(Function):
         # d(raw key slots 0..5 of node i) = sum over the entries of row i of their per-entry contributions
         seg_sum_rows(ck, plan.row_seg(), None, KEEP_VALID, out=dh1[:, 128:320])
         return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None, None, None
+
+
+def seg_sum_rows_bf16(src, seg, kind=None, keep=KEEP_VALID, out=None):
+    """seg_sum_rows for a contiguous bf16 source [n, C]: fp32 sums in segment order (hotk_seg_sum_rows_bf16)"""
+    beg, end, perm, maxlen = seg
+    n_seg = beg.numel()
+    if maxlen > SEG_SPLIT:
+        fine, group = refine_seg(seg, SEG_SPLIT)
+        part = seg_sum_rows_bf16(src, fine, kind, keep)
+        return seg_sum_rows(part, group, None, KEEP_VALID, out)
+    assert src.dtype == torch.bfloat16 and src.is_contiguous() and src.dim() == 2
+    n, C = src.shape
+    if out is None:
+        out = torch.empty(n_seg, C, dtype=torch.float32, device=src.device)
+    o, ldo, no, Co = rows2d(out)
+    assert o.data_ptr() == out.data_ptr() and no == n_seg and Co == C
+    call('hotk_seg_sum_rows_bf16', 2 * C * n + 4 * C * n_seg, p(src), C, p(beg), p(end), p(perm), p(kind), keep, p(o), ldo,
+         n_seg, C, maxlen)
+    return out
+
+
+class AttnLayer22BF16(Function):
+    """KernelSelfAttn(2,2) at the fused shape in the bf16 STORAGE mode (BASELINE north_star: bf16 held to 2e-2; the
+    reference trains in fp32 only): out = skip + mask(fc_o(cat(att_1..att_10))) from the layer input x [R, D] and the
+    node-level projection h1 = fc_1(G) (fp32).  The wide entry-level tensors -- h2 = fc_2(G) [R, 8 dqk + D], v = fc_v(x)
+    [R, 10 dv], att [R, 10 dv] and their gradients datt, dh2, dv, ck -- live in bf16; every product accumulates in fp32
+    (library bf16 GEMMs, hotk_attn22_forward / _backward with storage = bf16, fp32 segment sums), node-level tensors,
+    parameters, the layer input and output stay fp32.  Same factored Linear(2,2,'light') as ops.Linear22Light
+    (models/sparse/linear.py:143-161) and the same core as ops.AttnCore22 (kernelattn.py:119-159)."""
+
+    @staticmethod
+    def forward(ctx, x, h1, W2, b_off, b_diag, Wv, bv, Wo, bo, proj, plan, drop_p=0., mu_p=0.):
+        _lib.require_device(x)
+        _lib.require_unsharded(plan, 'the bf16 storage mode')
+        bf = torch.bfloat16
+        dev = x.device
+        R, Nn = plan.R, plan.Nn
+        D = x.size(-1)
+        C = W2.size(1)
+        assert C == 256 + D and W2.size(0) == 5 * D and Wv.shape == (320, D) and Wo.shape == (D, 320)
+        assert D % 4 == 0, 'bf16 rows are moved four channels at a time'
+        xs = x.reshape(R, D).contiguous()
+        padded = plan.Ev != plan.R
+        # fc_2 = Linear(2, 2, 'light') in factored form: node blocks per node in fp32, entry blocks as ONE bf16 GEMM
+        xd = gather_rows(xs, plan.diag_pos, Nn)
+        Wn = torch.cat([W2[0:D], W2[3 * D:4 * D], W2[4 * D:5 * D]], dim=1)
+        yn = xd @ Wn
+        x2 = torch.empty(R, 2 * D, dtype=torch.float32, device=dev)
+        call('hotk_basis22_pair_fwd', 4 * R * 4 * D, p(xs), D, p(plan.kind), p(plan.tpos), p(x2), 2 * D, R, D)
+        x2b = x2.to(bf)          # saved for the weight gradient (half the bytes of x2)
+        if thin_ok(R, 2 * D, C) and Nn * 3 * C < (1 << 32):
+            # entry GEMM (fp32 operands, split-bf16 MFMAs) with the assembly as its epilogue, rounded to bf16 at the store
+            h2 = torch.empty(R, C, dtype=bf, device=dev)
+            call('hotk_linear22_entry_fwd_bf16', R * (4 * 2 * D + 2 * C), p(x2), 2 * D, p(W2[D:3 * D].contiguous()), 2 * D, C,
+                 p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(h2), C, R, Nn)
+        else:
+            h2 = x2b @ W2[D:3 * D].to(bf)
+            call('hotk_assemble22_bf16', 4 * R * C, p(h2), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln),
+                 p(b_off), p(b_diag), R, C)
+        del x2
+        xb = xs.to(bf)
+        v = torch.addmm(bv.to(bf), xb, Wv.t().to(bf))
+        # the core
+        proj = proj.contiguous().float()
+        h1n = h1.reshape(Nn, 384).contiguous()
+        att = (torch.zeros if padded else torch.empty)(R, 320, dtype=bf, device=dev)
+        kvg = torch.empty(plan.B, 4, 25, 64, dtype=torch.float32, device=dev)
+        a = AttnCore22._args(plan, h1n, h2, v, proj, D)
+        a.storage = _lib.STORAGE_BF16
+        phik = AttnCore22._phik(plan, h1n, proj)
+        a.phik, a.ld_phik = phik.data_ptr(), 512
+        a.att, a.ld_att, a.kvg = att.data_ptr(), 320, kvg.data_ptr()
+        ws, nws = AttnCore22._workspace(plan, dev)
+        call('hotk_attn22_forward', plan.Ev * (2 * (8 * 32 + 10 * 32 + 10 * 32)) + 4 * Nn * 384, byref(a), p(ws), nws)
+        mu, keep = AttnCore22._drop_masks(plan, dev, drop_p, mu_p)
+        AttnCore22._drop_apply(att, plan, mu, keep, drop_p)
+        # fc_o + bias + skip path
+        y = (att @ Wo.t().to(bf)).float()
+        y += bo
+        y += h2[:, 256:]
+        if padded:
+            y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
+        ctx.save_for_backward(xb, xd, x2b, h1n, h2, v, att, kvg, phik, proj, W2, Wv, Wo)
+        ctx.plan, ctx.drop, ctx.shapes = plan, (mu, keep, drop_p), (x.shape, h1.shape)
+        ctx.has_b = (b_off is not None, b_diag is not None)
+        return y.view(*x.shape[:-1], D)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        xb, xd, x2b, h1n, h2, v, att, kvg, phik, proj, W2, Wv, Wo = ctx.saved_tensors
+        plan = ctx.plan
+        bf = torch.bfloat16
+        dev = h2.device
+        R, Nn = plan.R, plan.Nn
+        D, C = Wo.size(0), W2.size(1)
+        padded = plan.Ev != plan.R
+        d_out = d_out.contiguous().view(R, D)
+        dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
+        dyb = dy.to(bf)
+        datt = dyb @ Wo.to(bf)
+        dWo = wgrad(dyb, att)
+        dbo = dy.sum(0)
+        mu, keep, drop_p = ctx.drop
+        AttnCore22._drop_apply(datt, plan, mu, keep, drop_p)
+        dh1 = torch.empty(Nn, 384, dtype=torch.float32, device=dev)
+        dh2 = torch.empty(R, C, dtype=bf, device=dev)
+        dv = (torch.zeros if padded else torch.empty)(R, 320, dtype=bf, device=dev)
+        ck = torch.empty(R, 192, dtype=bf, device=dev)
+        dkvg = torch.empty_like(kvg)
+        a = AttnCore22._args(plan, h1n, h2, v, proj, D)
+        a.storage = _lib.STORAGE_BF16
+        a.phik, a.ld_phik, a.kvg = phik.data_ptr(), 512, kvg.data_ptr()
+        a.datt, a.ld_datt = datt.data_ptr(), 320
+        a.dout, a.ld_dout = dy.data_ptr(), D
+        a.dh1, a.ld_dh1 = dh1.data_ptr(), 384
+        a.dh2, a.ld_dh2 = dh2.data_ptr(), C
+        a.dv, a.ld_dv = dv.data_ptr(), 320
+        a.ck, a.dkvg = ck.data_ptr(), dkvg.data_ptr()
+        ws, nws = AttnCore22._workspace(plan, dev)
+        call('hotk_attn22_backward', plan.Ev * (2 * (8 * 32 * 2 + 10 * 32 * 3) + 25) + 4 * Nn * 384 * 2, byref(a), p(ws), nws)
+        seg_sum_rows_bf16(ck, plan.row_seg(), None, KEEP_VALID, out=dh1[:, 128:320])
+        # fc_v backward (bf16 GEMMs, fp32 sums)
+        dxv = dv @ Wv.to(bf)                                             # [R, D]
+        dWv = wgrad(dv, xb)                                              # [320, D]
+        dbv = dv.sum(0, dtype=torch.float32)
+        # fc_2 backward: g = dh2; padding rows of g were never written
+        g = dh2
+        if padded:
+            g = torch.where((plan.kind != 0).unsqueeze(1), g, torch.zeros((), dtype=bf, device=dev))
+        dyn = torch.empty(Nn, 3 * C, dtype=torch.float32, device=dev)
+        node_ok = (plan.nkind == 1).unsqueeze(1)
+        dyn[:, :C] = torch.where(node_ok, g.index_select(0, plan.diag_pos.clamp_min(0).long()).float(),
+                                 torch.zeros((), dtype=torch.float32, device=dev))
+        seg_sum_rows_bf16(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
+        seg_sum_rows_bf16(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
+        db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
+        db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
+        Wn = torch.cat([W2[0:D], W2[3 * D:4 * D], W2[4 * D:5 * D]], dim=1)
+        dxd = dyn @ Wn.t()
+        dx2 = (g @ W2[D:3 * D].t().to(bf)).float()
+        dx = torch.empty(R, D, dtype=torch.float32, device=dev)
+        call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D, p(dx),
+             D, R, D)
+        dx += dxv
+        dWn = wgrad(xd, dyn)
+        dW2 = torch.cat([dWn[:, 0:C], wgrad(x2b, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
+        xshape, h1shape = ctx.shapes
+        return (dx.view(xshape), dh1.view(h1shape), dW2, db_off, db_diag, dWv, dbv, dWo, dbo, None, None, None, None)
 
 
 def c_void_p_of(t, col):

@@ -254,6 +254,8 @@ int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t l
  * zero otherwise), dv [R,10*32]; padding rows of dh1/dh2/dv are left untouched.  dkvg [B,4,25,64] scratch.
  * workspace: hotk_attn22_workspace_bytes(B, Emax) (per-chunk partial graph sums).
  * ---------------------------------------------------------------------------------------------- */
+#define HOTK_STORAGE_F32 0
+#define HOTK_STORAGE_BF16 1
 typedef struct hotk_attn22_args {
   int64_t B, Emax, Nmax, R, Nn, D;
   int32_t H, m, d_head, c;
@@ -282,6 +284,11 @@ typedef struct hotk_attn22_args {
   float* nd0;   /* [Nn][2 slots][64] part 0: phi(q) . sums = [8 numerators | normaliser] per head (16 lanes), all-reduced */
   float* dd0;   /* [Nn][2][64] part 0: [d numerators | d normaliser] of the node queries, all-reduced */
   float diag_w; /* weight of a diagonal entry in the per-node sums (1/world: every rank holds all diagonal entries) */
+  /* storage type of the WIDE entry-level tensors h2, v, att, datt, dh2, dv, ck (their ld_* count elements of that type):
+   * HOTK_STORAGE_F32, or HOTK_STORAGE_BF16 = bf16 in memory with every product and sum in fp32 (BASELINE north_star's
+   * bf16 mode, held to 2e-2; the reference trains in fp32 only, --precision 32).  Node-level tensors (h1, phik, dh1, kvg,
+   * dout) stay fp32.  hotk_attn22_phase takes HOTK_STORAGE_F32 only. */
+  int32_t storage;
 } hotk_attn22_args;
 int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* bytes);
 int hotk_attn22_forward(const hotk_attn22_args* args, void* workspace, size_t ws_bytes, void* stream);
@@ -298,6 +305,21 @@ int hotk_attn22_backward(const hotk_attn22_args* args, void* workspace, size_t w
  * one stream are ordered and need no clearing in between (each call rewrites every partial it reads). */
 #define HOTK_ATTN22_STATIC_SCRATCH_BYTES (32u << 20)
 int hotk_attn22_forward_static(const hotk_attn22_args* args, void* stream);
+
+/* bf16-storage forms of two row primitives around the core (hotk_attn22_args.storage = HOTK_STORAGE_BF16; no reference
+ * counterpart beyond the fp32 forms they mirror): hotk_assemble22 in place on a bf16 z (yn and biases fp32, one rounding),
+ * hotk_seg_sum_rows over a bf16 source with fp32 sums.  C and the leading dimensions multiples of 4, rows 8-byte
+ * aligned (others: HOTK_EUNSUPPORTED). */
+int hotk_linear22_entry_fwd_bf16(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
+                                 int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
+                                 const float* b_off, const float* b_diag, void* Y, int64_t ldy, int64_t R, int64_t Nn,
+                                 void* stream);   /* hotk_linear22_entry_fwd with a bf16 Y: fp32 products, one rounding */
+int hotk_assemble22_bf16(void* z, int64_t ld, const float* yn, int64_t ld_yn, const uint8_t* kind, const int32_t* rown,
+                         const int32_t* coln, const float* b_off, const float* b_diag, int64_t R, int64_t C,
+                         void* stream);
+int hotk_seg_sum_rows_bf16(const void* src, int64_t ld_src, const int32_t* seg_begin, const int32_t* seg_end,
+                           const int32_t* perm, const uint8_t* kind, unsigned keep, float* out, int64_t ld_out,
+                           int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream);
 
 /* The same core in phases, for ONE graph whose entries are sharded over ranks (SURVEY 8e edge-shard; the reference has
  * no multi-device form of kernelattncoef.py:103-175, the sums are what its coalesce() builds on one device).  Sums over
