@@ -31,9 +31,10 @@ BYTES_PER_ENTRY = 96 * DQK + 224 * DV + 50
 BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEADS + 1)
 # HBM traffic of the fused core per valid entry on THIS workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
-# profiles/r01_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at 2 M entries (per-entry figures are size-independent)
-PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4903, 'hotk_attn22_backward': 8584}
-PMC_TRAFFIC_SOURCE = 'profiles/r01_pmc_traffic_attn22.txt'
+# profiles/r02_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at the benchmarked size (10 M entries; the
+# round-1 pass at 2 M entries gave 4903 / 8584: per-entry figures are size-independent)
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4886, 'hotk_attn22_backward': 8575}
+PMC_TRAFFIC_SOURCE = 'profiles/r02_pmc_traffic_attn22.txt'
 
 
 def build_structure(n_graphs, distinct=512, seed=1234):
@@ -341,8 +342,9 @@ def main():
             traffic = PMC_TRAFFIC_BYTES_PER_ENTRY.get(prof_name)
             roof = {'bound': 'hbm', 'kernel': prof_name, 'achieved': ach, 'peak': HBM_PEAK / 1e9, 'unit': 'GB/s',
                     'frac': ach * 1e9 / HBM_PEAK, 'traffic': None if traffic is None else traffic * n_entries,
-                    'traffic_source': 'NOT measured in this run: a constant from separate rocprofv3 --pmc passes at 2 M '
-                                      'entries (PMC_TRAFFIC_SOURCE), B/entry x entries of this launch',
+                    'traffic_source': 'NOT measured in this run (a bench cannot profile itself): constant from separate rocprofv3 '
+                                      '--pmc FETCH_SIZE / WRITE_SIZE passes at the benchmarked size (10 M entries, '
+                                      'traffic_profile), B/entry x entries of this launch; fp32 storage',
                     'traffic_profile': PMC_TRAFFIC_SOURCE,
                     'launches': calls,
                     'avg_launch_ms': tot_ms / max(calls, 1),
