@@ -213,8 +213,11 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_bwd(const float* __
   float gmax = 0.f, gshare = 0.f;
   if (mode == HOTK_PHI_SOFTMAX_K) {
     gmax = gstat[0];
-    gshare = gstat[1] / fmaxf(gstat[2], 1.f);  // d loss / d(-max), evenly split over the maxima
+    gshare = gstat[1] / fmaxf(gstat[2], 1e-30f);  // d loss / d(-max), evenly split over the maxima
   }
+  // rows that every rank of an edge-sharded graph holds (everything but off-diagonal entries) take their share of the
+  // maximum's gradient with weight gstat[3] = 1/world: the caller adds the gradients of replicated rows over the ranks
+  const float wrep = (mode == HOTK_PHI_SOFTMAX_K && gstat[3] > 0.f) ? gstat[3] : 1.f;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     int64_t r = t / C;
     int c = (int)(t - r * C);
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_bwd(const float* __
         float pre = proj_dot(xr, P + mm * d, d, scale);
         float a = live ? gr[mm] * ratio * expf(pre - diag - gmax) : 0.f;
         asum += a;
-        float dpre = a - ((pre == gmax) ? gshare : 0.f);
+        float dpre = a - ((pre == gmax) ? gshare * ((kind && kind[r] == 2) ? 1.f : wrep) : 0.f);
         acc = fmaf(dpre, P[mm * d + k], acc);
       }
     }
@@ -316,6 +319,7 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_key_bwd_partial(const float
   __shared__ float red[PHI_THREADS / 64];
   stage_proj(P, proj, m * d);
   const float gmax = gstat[0];
+  const float wrep = gstat[3] > 0.f ? gstat[3] : 1.f;   // weight of a maximum on a row every rank holds (see k_phi_softmax_bwd)
   const int64_t total = n * HH;
   float s = 0.f, cnt = 0.f;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_key_bwd_partial(const float
     const float diag = nrm * 0.5f * scale * scale;
     for (int mm = 0; mm < m; ++mm) {
       float pre = proj_dot(xr, P + mm * d, d, scale);
-      if (pre == gmax) cnt += 1.f;
+      if (pre == gmax) cnt += (kind && kind[r] == 2) ? 1.f : wrep;
       if (live) s += gr[mm] * ratio * expf(pre - diag - gmax);
     }
   }

@@ -92,6 +92,11 @@ class ShardInfo:
             _all_reduce(t, dist.ReduceOp.SUM, self.group)
         return t
 
+    def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.world > 1:
+            _all_reduce(t, dist.ReduceOp.MAX, self.group)
+        return t
+
 
 def shard_owner(i: torch.Tensor, j: torch.Tensor, world: int) -> torch.Tensor:
     """owner rank of off-diagonal entry (i,j): a function of the unordered pair, so transposes stay together"""

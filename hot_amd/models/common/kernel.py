@@ -73,6 +73,7 @@ class KernelFeatureMap(nn.Module):
             return
         self.calls_since_last_redraw += 1
 
-    def forward(self, x, is_query=False, kind=None, keep=_lib.KEEP_VALID):
-        """x [..., k*D] -> [..., k*m] (k head chunks of width D each; k = 1 reproduces the reference call)."""
-        return ops.Phi.apply(x, self.projection_matrix, kind, keep, self.dim_features, self.mode(is_query))
+    def forward(self, x, is_query=False, kind=None, keep=_lib.KEEP_VALID, shard=None):
+        """x [..., k*D] -> [..., k*m] (k head chunks of width D each; k = 1 reproduces the reference call).
+        shard: the edge-shard context of the batch's plan (hot_amd.dist.ShardInfo) or None."""
+        return ops.Phi.apply(x, self.projection_matrix, kind, keep, self.dim_features, self.mode(is_query), shard)

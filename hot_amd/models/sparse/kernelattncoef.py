@@ -24,11 +24,9 @@ class KernelFeatureMapWrapper(nn.Module):
         matter).  One fused kernel instead of split/stack/einsum/masked_fill/cat (kernelattncoef.py:19-28)."""
         assert self.feature_map.dim_features == self.dim_qk_head
         plan = G.plan
-        if not is_query and not self.feature_map.generalized_attention:
-            # the softmax key map subtracts ONE maximum over every row of the batch (common/kernel.py:112)
-            _lib.require_unsharded(plan, 'the softmax feature map of keys (att_cfg="kernel")')
         kind, keep = (plan.kind, KEEP_OFFDIAG) if G.order > 1 else (plan.nkind, KEEP_DIAG)
-        v = self.feature_map(G.values, is_query, kind, keep)
+        # edge-shard mode: the softmax key map's single maximum (common/kernel.py:112) is MAX-all-reduced inside ops.Phi
+        v = self.feature_map(G.values, is_query, kind, keep, getattr(plan, 'shard', None))
         return batch_like(G, v, skip_masking=True)
 
 

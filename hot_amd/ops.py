@@ -326,7 +326,7 @@ class Phi(Function):
     KernelFeatureMap.{generalized_map,softmax_map} (models/common/kernel.py:81-138)."""
 
     @staticmethod
-    def forward(ctx, x, proj, kind, keep, d, mode):
+    def forward(ctx, x, proj, kind, keep, d, mode, shard=None):
         xs, ld, n, C = rows2d(x)
         m = proj.size(0)
         assert proj.size(1) == d and C % d == 0
@@ -339,9 +339,15 @@ class Phi(Function):
             check(lib().hotk_phi_stats_workspace_bytes(n, HH, m, byref(need)), 'hotk_phi_stats_workspace_bytes')
             ws = torch.empty(need.value, dtype=torch.uint8, device=x.device)
             call('hotk_phi_key_stats', 4 * n * HH * d, p(xs), ld, p(proj), n, HH, d, m, p(gstat), p(ws), need.value)
+            if shard is not None and shard.world > 1:
+                # the key map subtracts ONE maximum over every row of the batch (common/kernel.py:112): across the
+                # shards of a graph that is the MAX over ranks; replicated rows weigh 1/world in the backward pass
+                shard.all_reduce_max_(gstat[0:1])
+                gstat[3] = 1.0 / shard.world
         out = torch.empty(*x.shape[:-1], HH * m, dtype=x.dtype, device=x.device)
         call('hotk_phi_fwd', 4 * n * HH * (d + m), p(xs), ld, p(proj), p(kind), keep, p(out), HH * m, n, HH, d, m, mode, p(gstat))
         ctx.save_for_backward(xs, proj, kind, gstat)
+        ctx.shard = shard
         ctx.cfg = (ld, n, HH, d, m, mode, keep, x.shape)
         return out
 
@@ -358,10 +364,12 @@ class Phi(Function):
             ws = torch.empty(need.value, dtype=torch.uint8, device=g.device)
             call('hotk_phi_key_bwd_stats', 4 * n * HH * (d + m), p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, n, HH, d, m, p(gstat),
                                                p(ws), need.value)
+            if ctx.shard is not None and ctx.shard.world > 1:
+                ctx.shard.all_reduce_(gstat[1:3])      # total gradient of the maximum and the number of maxima
         dx = torch.empty(xshape, dtype=g.dtype, device=g.device)
         call('hotk_phi_bwd', 4 * n * HH * (2 * d + m), p(xs), ld, p(proj), p(kind), keep, p(gs), ldg, p(dx), HH * d, n, HH, d, m, mode,
                                  p(gstat))
-        return dx, None, None, None, None, None
+        return dx, None, None, None, None, None, None
 
 
 class Basis22Light(Function):

@@ -166,7 +166,10 @@ int hotk_phi_stats_workspace_bytes(int64_t n, int HH, int m, size_t* bytes);
 int hotk_phi_key_stats(const float* x, int64_t ld_x, const float* proj, int64_t n, int HH, int d, int m,
                        float* gstat, void* workspace, size_t ws_bytes, void* stream);
 /* gstat[1] = sum over rows in keep of dphi * ratio * exp(.) (d loss / d(-max)), gstat[2] = number of
- * elements equal to the max; needed by the key-branch backward. */
+ * elements equal to the max; needed by the key-branch backward.
+ * Edge-shard mode (one graph over several ranks): gstat[0] is MAX-all-reduced after hotk_phi_key_stats and
+ * gstat[1], gstat[2] are SUM-all-reduced after this call; gstat[3] = 1/world (0 = not sharded) weights maxima that sit on
+ * rows every rank holds (kind != 2), in the count here and in hotk_phi_bwd's share of the maximum's gradient. */
 int hotk_phi_key_bwd_stats(const float* x, int64_t ld_x, const float* proj, const uint8_t* kind, unsigned keep,
                            const float* dphi, int64_t ld_dphi, int64_t n, int HH, int d, int m, float* gstat,
                            void* workspace, size_t ws_bytes, void* stream);

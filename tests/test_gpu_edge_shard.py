@@ -37,18 +37,18 @@ def _graph(seed=3, n=300, n_pairs=1200):
     return torch.randn(n, 16, generator=g), ei, torch.randn(ei.size(1), 16, generator=g), g
 
 
-def _layer():
+def _layer(generalized=True):
     from hot_amd.models.common import KernelFeatureMap
     from hot_amd.models.sparse import KernelSelfAttn
     torch.manual_seed(0)
-    return KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8, generalized_attention=True)).to(DEV)
+    return KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8, generalized_attention=generalized)).to(DEV)
 
 
 def _rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-12))
 
 
-def _worker(rank, world, port, q, fused):
+def _worker(rank, world, port, q, fused, generalized=True):
     import datetime
     import torch.distributed as dist
     os.environ['MASTER_ADDR'] = '127.0.0.1'
@@ -65,17 +65,17 @@ def _worker(rank, world, port, q, fused):
         Rw_cpu = torch.randn(n + E, 32, generator=g)              # loss weights per global row (nodes, then edges)
         Rw = Rw_cpu.to(DEV)
         # the WHOLE graph on the CPU oracle (pinned restatement of the reference): the reference every rank is held to
-        layer = _layer()
+        layer = _layer(generalized)
         sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
               for k, v in layer.state_dict().items()}
         GO = O.build_batch(nf, ei, ef, [n], [E])
         xo = GO.values.clone().requires_grad_(True)
-        yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, 32, 32, 4, 'default', True)
+        yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, 32, 32, 4, 'default', generalized)
         (yo.values[0] * Rw_cpu).sum().backward()
         ref_y, ref_gx = yo.values[0].detach().to(DEV), xo.grad[0].to(DEV)
         ref_gp = {k: sd[k].grad.to(DEV) for k, _ in layer.named_parameters()}
         # this rank's shard on the HIP path
-        layer2 = _layer()
+        layer2 = _layer(generalized)
         layer2.use_fused = fused
         Gs, own = shard_graph(nf.to(DEV), ei.to(DEV), ef.to(DEV), world, rank)
         rows = torch.cat([torch.arange(n, device=DEV), n + own])         # global row of every local row
@@ -103,8 +103,7 @@ def _worker(rank, world, port, q, fused):
         from hot_amd.models import sparse as ms
         refused = 0
         for make in (lambda: ms.Linear(2, 2, 32, 8, cfg='default'), lambda: ms.Linear(2, 0, 32, 8, cfg='light'),
-                     lambda: ms.SelfAttn(2, 0, 32, 32, 32, 4),
-                     lambda: ms.KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8))):
+                     lambda: ms.SelfAttn(2, 0, 32, 32, 32, 4)):
             try:
                 make().to(DEV)(Gs)
             except _lib.HotkError as exc:
@@ -129,13 +128,15 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize('world,fused', [(2, True), (2, False), (4, True)])
-def test_edge_shard_matches_oracle_on_whole_graph(world, fused):
+@pytest.mark.parametrize('world,fused,generalized', [(2, True, True), (2, False, True), (4, True, True), (2, False, False)])
+def test_edge_shard_matches_oracle_on_whole_graph(world, fused, generalized):
+    """generalized = False: the softmax feature map, whose key branch subtracts ONE maximum over the whole batch
+    (common/kernel.py:112) -- MAX-all-reduced across the shards, its gradient SUM-all-reduced (ops.Phi)"""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused), daemon=True) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, fused, generalized), daemon=True) for r in range(world)]
     for p in procs:
         p.start()
     try:
@@ -156,7 +157,7 @@ def test_edge_shard_matches_oracle_on_whole_graph(world, fused):
     for rank, r in results.items():
         assert r['y'] < 1e-5, (rank, r)
         assert r['gx_edges_bad_rows'] <= 5e-3 and r['gx_nodes_bad_rows'] <= 5e-3 and r['gp'] < 1e-3, (rank, r)
-        assert r['refused'] == 4, (rank, r)
+        assert r['refused'] == 3, (rank, r)
 
 
 def test_fused_phases_single_rank_equal_one_pass():
