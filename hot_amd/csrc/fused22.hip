@@ -137,12 +137,34 @@ __device__ __forceinline__ float rot_dot(float v, const float (&rot)[NM]) {
   return a0;
 }
 
+// The same contraction when only EIGHT outputs per head exist (d(raw q), d(raw k), dV: lanes x and x + 8 both own output
+// x & 7): lane x sums the eight features {x, x-1, .., x-7} (mod 16), lane x + 8 the other eight, and one more rotation
+// by 8 adds the two halves -- 10 instructions instead of 17 and tables of 8 instead of 16 registers.
+constexpr int NR8 = 8;
+__device__ __forceinline__ float rot_dot8(float v, const float (&rot)[NR8]) {
+  float a0, a1;
+  asm volatile("v_mul_f32_e32 %0, %2, %3\n\t"
+               "s_nop 0\n\t"
+               "v_mul_f32_dpp %1, %2, %4" HOTK_DPP_ROR(1)
+               "v_fmac_f32_dpp %0, %2, %5" HOTK_DPP_ROR(2)
+               "v_fmac_f32_dpp %1, %2, %6" HOTK_DPP_ROR(3)
+               "v_fmac_f32_dpp %0, %2, %7" HOTK_DPP_ROR(4)
+               "v_fmac_f32_dpp %1, %2, %8" HOTK_DPP_ROR(5)
+               "v_fmac_f32_dpp %0, %2, %9" HOTK_DPP_ROR(6)
+               "v_fmac_f32_dpp %1, %2, %10" HOTK_DPP_ROR(7)
+               "v_add_f32_e32 %0, %0, %1"
+               : "=&v"(a0), "=&v"(a1)
+               : "v"(v), "v"(rot[0]), "v"(rot[1]), "v"(rot[2]), "v"(rot[3]), "v"(rot[4]), "v"(rot[5]), "v"(rot[6]),
+                 "v"(rot[7]));
+  return a0 + ror<8>(a0);
+}
+
 struct Lane {
   int lane, h, x;
   float ps[DH];  // F layout: P[x][:] * d^-1/4
 };
 struct LaneB : Lane {
-  float pr[NM];  // rotated projection: P[(x - k) & 15][x & 7] * d^-1/4   (backward kernels only)
+  float pr[NR8];  // rotated projection: P[(x - k) & 15][x & 7] * d^-1/4, k < 8 (rot_dot8; backward kernels only)
 };
 
 constexpr float PSCALE = 0.59460355750136051f;  // 8^-1/4
@@ -163,7 +185,7 @@ __device__ __forceinline__ LaneB make_lane_b(const float* __restrict__ proj) {
   LaneB L;
   init_lane(L, proj);
 #pragma unroll
-  for (int k = 0; k < NM; ++k) L.pr[k] = proj[ror_src(L.x, k) * DH + (L.x & 7)] * PSCALE;
+  for (int k = 0; k < NR8; ++k) L.pr[k] = proj[ror_src(L.x, k) * DH + (L.x & 7)] * PSCALE;
   return L;
 }
 
@@ -176,6 +198,9 @@ __device__ __forceinline__ float pre_x(const Lane& L, const float (&x)[DH]) {
   for (int j = 1; j < DH; ++j) s = fmaf(x[j], L.ps[j], s);
   return s;
 }
+
+// d(raw q or k)[x & 7] = sum_mm dpre[mm] P[mm][x & 7] (all 16 lanes of the head hold it)
+__device__ __forceinline__ float proj_back(const LaneB& L, float dpre) { return rot_dot8(dpre, L.pr); }
 
 // the 8-float slice of head h of a 32-float slot staged in the wave's LDS row
 __device__ __forceinline__ void slice8(const Lane& L, const float* lds_slot, float (&o)[8]) {
@@ -218,8 +243,8 @@ __device__ __forceinline__ void kv_acc_scaled(float (&kv)[NC + 1], float phi, co
 // twice, 16 rows apart, so that row (x - k) & 15 is the plain row x + 16 - k and all 16 reads use immediate offsets.
 // DUP: lanes 8..15 repeat channels 0..7 (gradient of the values) instead of holding the normaliser channel.
 constexpr int KVBUF_FLOATS = NH * 32 * (NC + 1);
-template <bool DUP>
-__device__ __forceinline__ void kv_to_rot(const Lane& L, float* kvbuf, const float (&kv)[NC + 1], float (&rot)[NM]) {
+template <bool DUP, int NK = DUP ? NR8 : NM>   // DUP tables feed rot_dot8: rotations 0..7 only
+__device__ __forceinline__ void kv_to_rot(const Lane& L, float* kvbuf, const float (&kv)[NC + 1], float (&rot)[NK]) {
   wave_fence();
   float* w = kvbuf + (L.h * 32 + L.x) * (NC + 1);
 #pragma unroll
@@ -232,11 +257,11 @@ __device__ __forceinline__ void kv_to_rot(const Lane& L, float* kvbuf, const flo
   if (HOTK_ROR_DIR < 0) {
     const float* r = kvbuf + (L.h * 32 + L.x + 1) * (NC + 1) + cidx;
 #pragma unroll
-    for (int k = 0; k < NM; ++k) rot[k] = r[(15 - k) * (NC + 1)];
+    for (int k = 0; k < NK; ++k) rot[k] = r[(15 - k) * (NC + 1)];
   } else {
     const float* r = kvbuf + (L.h * 32 + L.x) * (NC + 1) + cidx;
 #pragma unroll
-    for (int k = 0; k < NM; ++k) rot[k] = r[k * (NC + 1)];
+    for (int k = 0; k < NK; ++k) rot[k] = r[k * (NC + 1)];
   }
 }
 
@@ -276,55 +301,55 @@ __device__ __forceinline__ void apply_bwd(const LaneB& L, const float (&q)[DH], 
   for (int c = 0; c < NC; ++c) dkv[c] = fmaf(pi, g[c], dkv[c]);
   dkv[NC] = fmaf(phi, dden, dkv[NC]);
   const float dpre = pre > 0.f ? dphi : 0.f;
-  const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) stS(dq + L.h * DH + L.x, d);
+  const float d = proj_back(L, dpre);
+  stS(dq + L.h * DH + (L.x & 7), d);   // all 16 lanes of a head hold output x & 7: lanes x and x + 8 store the same value
 }
 
 // backward of one KV accumulation term: dV (32 floats at dv, may be null; drot = C layout of dKV with DUP) and
 // d(raw key) (32 floats at dk)
 template <class VT, class KT>
 __device__ __forceinline__ void kv_bwd(const LaneB& L, const float (&k)[DH], const float (&val)[NC],
-                                       const float (&dkv)[NC + 1], const float (&drot)[NM], VT* __restrict__ dv,
+                                       const float (&dkv)[NC + 1], const float (&drot)[NR8], VT* __restrict__ dv,
                                        KT* __restrict__ dk) {
   const float pre = pre_x(L, k);
   const float phi = phi_of(pre);
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
-  const float dvv = rot_dot(phi, drot);
-  if (dv && L.x < NC) stS(dv + L.h * NC + L.x, dvv);
+  const float dvv = rot_dot8(phi, drot);
+  if (dv) stS(dv + L.h * NC + (L.x & 7), dvv);
   const float dpre = pre > 0.f ? dphi : 0.f;
-  const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) stS(dk + L.h * DH + L.x, d);
+  const float d = proj_back(L, dpre);
+  stS(dk + L.h * DH + (L.x & 7), d);
 }
 
 // the same for a key whose feature phi comes from the per-node table (pre > 0  <=>  phi > eps)
 template <class VT, class KT>
 __device__ __forceinline__ void kv_bwd_phi(const LaneB& L, float phi, const float (&val)[NC], const float (&dkv)[NC + 1],
-                                           const float (&drot)[NM], VT* __restrict__ dv, KT* __restrict__ dk) {
+                                           const float (&drot)[NR8], VT* __restrict__ dv, KT* __restrict__ dk) {
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
-  const float dvv = rot_dot(phi, drot);
-  if (dv && L.x < NC) stS(dv + L.h * NC + L.x, dvv);
+  const float dvv = rot_dot8(phi, drot);
+  if (dv) stS(dv + L.h * NC + (L.x & 7), dvv);
   const float dpre = phi > PHI_EPS ? dphi : 0.f;
-  const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) stS(dk + L.h * DH + L.x, d);
+  const float d = proj_back(L, dpre);
+  stS(dk + L.h * DH + (L.x & 7), d);
 }
 
 // the same for an entry that enters the column sum with weight w (split-phase mode: the replicated diagonal entry)
 template <class VT, class KT>
 __device__ __forceinline__ void kv_bwd_phi_w(const LaneB& L, float phi, float w, const float (&val)[NC],
-                                             const float (&dkv)[NC + 1], const float (&drot)[NM], VT* __restrict__ dv,
+                                             const float (&dkv)[NC + 1], const float (&drot)[NR8], VT* __restrict__ dv,
                                              KT* __restrict__ dk) {
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
-  const float dvv = rot_dot(phi * w, drot);
-  if (dv && L.x < NC) stS(dv + L.h * NC + L.x, dvv);
+  const float dvv = rot_dot8(phi * w, drot);
+  if (dv) stS(dv + L.h * NC + (L.x & 7), dvv);
   const float dpre = phi > PHI_EPS ? dphi * w : 0.f;
-  const float d = rot_dot(dpre, L.pr);
-  if (L.x < DH) stS(dk + L.h * DH + L.x, d);
+  const float d = proj_back(L, dpre);
+  stS(dk + L.h * DH + (L.x & 7), d);
 }
 
 template <class OT>
@@ -414,9 +439,10 @@ __device__ __forceinline__ void kvg_load(const Lane& L, const float* __restrict_
 #pragma unroll
   for (int c = 0; c <= NC; ++c) kv[c] = slot[c * 64 + L.lane];
 }
-__device__ __forceinline__ void kvg_load_rot(const Lane& L, const float* __restrict__ slot, float (&rot)[NM]) {
+template <int NK>
+__device__ __forceinline__ void kvg_load_rot(const Lane& L, const float* __restrict__ slot, float (&rot)[NK]) {
 #pragma unroll
-  for (int k = 0; k < NM; ++k) rot[k] = slot[(NC + 1 + k) * 64 + L.lane];
+  for (int k = 0; k < NK; ++k) rot[k] = slot[(NC + 1 + k) * 64 + L.lane];
 }
 // partial sums of one chunk: [4][9][64]
 __device__ __forceinline__ void part_store(const Lane& L, float* __restrict__ base, const float (&kv)[NC + 1]) {
@@ -613,9 +639,9 @@ __device__ __forceinline__ void load_kv3(const Lane& L, const A& a, int32_t e, i
   r[0] = pk[0];
   r[1] = pk[64];
   const bool lo = L.lane < 32;
-  const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
   // a missing transposed entry reads the entry's own row instead (any valid address) and is masked at USE time:
   // selecting on the loaded value here would make the prefetch synchronous
+  const int32_t row = (P == 2) ? (lo ? te : e) : (lo ? e : te);
   r[2] = ldS((const ST*)a.v + rowoff(row < 0 ? e : row, a.ld_v) + 2 * P * SLOT + L.lane);
 }
 
@@ -921,7 +947,7 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
   if (rb <= ra) return;
   const bool lo = L.lane < 32;
   const SV<ST> S(a);
-  float d0[NC + 1], d1[NC + 1], t0[NM], t1[NM];
+  float d0[NC + 1], d1[NC + 1], t0[NR8], t1[NR8];
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), d0);
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), d1);
   kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), t0);
@@ -1039,8 +1065,8 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
           dkv[s][c] = phi * dn[c];
         }
         dkv[s][NC] = phi * dd;
-        const float d = rot_dot(pre > 0.f ? dphi : 0.f, L.pr);
-        if (L.x < DH) dq[s * SLOT + L.h * DH + L.x] = d;
+        const float d = proj_back(L, pre > 0.f ? dphi : 0.f);
+        dq[s * SLOT + L.h * DH + (L.x & 7)] = d;
       }
     } else if constexpr (MODE == 2) {
       kvg_load(L, dkvn_slot<P>(a, n, 0), dkv[0]);
@@ -1113,7 +1139,7 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
     }
     // key / value side of this part's two column sums: dV of the plain slot goes to row e, dV of the transposed
     // slot to row te; d(raw key) contributions go to ck[e] (summed per row node afterwards)
-    float drot0[NM], drot1[NM];
+    float drot0[NR8], drot1[NR8];
     kv_to_rot<true>(L, kvbuf, dkv[0], drot0);
     kv_to_rot<true>(L, kvbuf, dkv[1], drot1);
     for_col_entries<ST, P, (MODE >= 2)>(L, a, stage, (int32_t)n, [&](int32_t e, int32_t te, float phi0, float phi1, float w) __attribute__((always_inline)) {
