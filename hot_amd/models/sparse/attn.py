@@ -69,12 +69,12 @@ class SelfAttn(nn.Module):
         k_2 = self.fc_2(G)                                   # [B, |E|, dqk]
         v = self._values(G)
         plan = G.plan
-        _lib.require_unsharded(plan, 'the order-0 softmax readout over entries')
         # set -> vector over the nodes, graph -> vector over the off-diagonal entries (loop mask, attncoef.py:45-48)
         att_1 = ops.SoftmaxPool.apply(q_a, k_1.values, d(v[0]).values, plan.graph_seg(1), plan.nkind, KEEP_DIAG,
                                       self.n_heads)
+        # (edge-shard mode: the nodes are replicated on every rank, the off-diagonal entries are spread over the ranks)
         att_2 = ops.SoftmaxPool.apply(q_b, k_2.values, v[1].values, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG,
-                                      self.n_heads)
+                                      self.n_heads, ops.shard_of(plan))
         return non_att + self.fc_o(self.dropout(torch.cat([att_1, att_2], -1)))
 
     def forward(self, G: B):

@@ -38,17 +38,25 @@ def pool_1_to_0(G, normalize):
     return V
 
 
+def offdiag_count(plan, n_nodes, n_edges, dtype, device):
+    """[B,1] number of off-diagonal entries per graph; in edge-shard mode the count over every rank's entries"""
+    if not hasattr(plan, '_eo_graph'):
+        e = (_counts(n_edges, torch.float32, device) - _counts(n_nodes, torch.float32, device))[:, None].clone()
+        shard = ops.shard_of(plan)
+        plan._eo_graph = e if shard is None else shard.all_reduce_(e)
+    return plan._eo_graph.to(dtype)
+
+
 def pool_2_to_0(G, normalize):
-    """[B,E,D] -> [B,2D]: trace pool and off-diagonal pool (linear.py:85-97)."""
+    """[B,E,D] -> [B,2D]: trace pool and off-diagonal pool (linear.py:85-97).  Edge-shard mode: the diagonal is replicated
+    on every rank (its pool is complete locally), the off-diagonal pool is added over the ranks."""
     plan = G.plan
-    _lib.require_unsharded(plan, 'the order-2 -> order-0 pooling basis')
     eg = plan_entry_graph(plan)
     V1 = ops.SegSumRows.apply(G.values, plan.graph_seg(2), plan.kind, KEEP_DIAG, eg)
-    V2 = ops.SegSumRows.apply(G.values, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG, eg)
+    V2 = ops.entry_sum(ops.SegSumRows.apply(G.values, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG, eg), plan)
     if normalize:
         n = _counts(G.n_nodes, V1.dtype, V1.device)[:, None]
-        e = _counts(G.n_edges, V1.dtype, V1.device)[:, None] - n
-        V1, V2 = _safe_div(V1, n), _safe_div(V2, e)
+        V1, V2 = _safe_div(V1, n), _safe_div(V2, offdiag_count(plan, G.n_nodes, G.n_edges, V1.dtype, V1.device))
     return torch.cat([V1, V2], -1)
 
 
@@ -73,8 +81,12 @@ def _plan_counts(plan, n_nodes, n_edges):
         valid = (plan.nkind == 1)
         od = ((plan.row_ptr[1:] - plan.row_ptr[:-1] - 1).clamp(min=0) * valid).to(torch.float32).unsqueeze(1)
         idg = ((plan.col_ptr[1:] - plan.col_ptr[:-1] - 1).clamp(min=0) * valid).to(torch.float32).unsqueeze(1)
+        shard = ops.shard_of(plan)
+        if shard is not None:      # degrees over every rank's entries (each CSR row holds the replicated diagonal once)
+            shard.all_reduce_(od)
+            shard.all_reduce_(idg)
         n_g = torch.as_tensor(n_nodes, **f).unsqueeze(1)                            # [B,1]
-        eo_g = torch.as_tensor(n_edges, **f).unsqueeze(1) - n_g
+        eo_g = offdiag_count(plan, n_nodes, n_edges, torch.float32, dev)
         ng = plan_node_graph(plan).long()
         eg = plan_entry_graph(plan).long()
         ri, ci = plan.rown.clamp(min=0).long(), plan.coln.clamp(min=0).long()
@@ -89,16 +101,23 @@ def _nrm(x, cnt, normalize):
 
 
 def _order2_sums(G):
-    """diag [Nn,D], off-diagonal row sums R and column sums C [Nn,D], trace T and off-diagonal total S [B,D]."""
+    """diag [Nn,D], off-diagonal row sums R and column sums C [Nn,D], trace T and off-diagonal total S [B,D].
+    Edge-shard mode (hot_amd.dist): R, C and S are sums over off-diagonal entries, which are spread over the ranks --
+    the local sums are all-reduced in ONE flat buffer (ops.AllReduceSum: forward and gradient); diag and T come from the
+    diagonal entries, which every rank holds."""
     plan = G.plan
-    _lib.require_unsharded(plan, "the pooling basis of Linear(cfg='default')")
     A = G.values.reshape(plan.R, -1)
+    D = A.size(1)
     diag = ops.GatherRows.apply(A, plan.diag_pos, plan.diag_node, plan.Nn)
     R = ops.SegSumRows.apply(A, plan.row_seg(), plan.kind, KEEP_OFFDIAG, plan.rown)
     C = ops.SegSumRows.apply(A, plan.col_seg(), plan.kind, KEEP_OFFDIAG, plan.coln)
     eg = plan_entry_graph(plan)
     T = ops.SegSumRows.apply(A, plan.graph_seg(2), plan.kind, KEEP_DIAG, eg)
     S = ops.SegSumRows.apply(A, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG, eg)
+    shard = ops.shard_of(plan)
+    if shard is not None:
+        flat = ops.AllReduceSum.apply(torch.cat([R.reshape(-1), C.reshape(-1), S.reshape(-1)]), shard)
+        R, C, S = flat[:R.numel()].view_as(R), flat[R.numel():2 * R.numel()].view_as(C), flat[2 * R.numel():].view_as(S)
     return A, diag, R, C, T, S
 
 

@@ -9,12 +9,17 @@ from .basis import plan_entry_graph, plan_node_graph
 
 
 def _graph_sum(G, keep):
+    """sum over the kept rows of each graph.  Edge-shard mode: nodes and diagonal entries are replicated on every rank
+    (complete locally), off-diagonal entries are spread over the ranks (their sum is all-reduced)."""
     plan = G.plan
-    if G.order == 2:
-        _lib.require_unsharded(plan, 'a graph-level pool over entries')
     kind = plan.nkind if G.order == 1 else plan.kind
     rg = plan_node_graph(plan) if G.order == 1 else plan_entry_graph(plan)
-    return ops.SegSumRows.apply(G.values, plan.graph_seg(G.order), kind, keep, rg)
+    seg = plan.graph_seg(G.order)
+    if G.order == 1 or keep != KEEP_VALID or ops.shard_of(plan) is None:
+        x = ops.SegSumRows.apply(G.values, seg, kind, keep, rg)
+        return ops.entry_sum(x, plan) if (G.order == 2 and keep == KEEP_OFFDIAG) else x
+    return (ops.SegSumRows.apply(G.values, seg, kind, KEEP_DIAG, rg) +
+            ops.entry_sum(ops.SegSumRows.apply(G.values, seg, kind, KEEP_OFFDIAG, rg), plan))
 
 
 class SumPool(nn.Module):
@@ -47,5 +52,6 @@ class AvgPool(nn.Module):
         n_inv = (n + 1e-5).pow(-1).unsqueeze(1)
         if self.order == 1:
             return n_inv * _graph_sum(G, KEEP_VALID)
-        e_inv = (_counts(G.n_edges, torch.long, dev) - n + 1e-5).pow(-1).unsqueeze(1)
+        from .basis import offdiag_count
+        e_inv = (offdiag_count(G.plan, G.n_nodes, G.n_edges, torch.float32, dev) + 1e-5).pow(-1)
         return _graph_sum(G, KEEP_DIAG) * n_inv + _graph_sum(G, KEEP_OFFDIAG) * e_inv

@@ -598,6 +598,35 @@ class KernelAttn(Function):
         return dq.view(q.shape), dk.view(k.shape), dv.view(ctx.vshape), None, None, None, None, None, None
 
 
+class AllReduceSum(Function):
+    """Edge-shard mode (hot_amd.dist): a sum over ENTRIES is partial on a rank; forward adds the partial sums
+    of all ranks (RCCL SUM), backward adds the gradients that the ranks' local losses send into the sum -- the
+    all-reduce is its own adjoint.  Replicated quantities (node tables, diagonal entries, graph-level vectors) never
+    pass through it: their gradients stay partial per rank and are added over ranks by the caller, like the parameter
+    gradients."""
+
+    @staticmethod
+    def forward(ctx, x, shard):
+        ctx.shard = shard
+        return shard.all_reduce_(x.contiguous().clone())
+
+    @staticmethod
+    def backward(ctx, g):
+        return ctx.shard.all_reduce_(g.contiguous().clone()), None
+
+
+def shard_of(plan):
+    """the edge-shard context of a plan when more than one rank holds the graph, else None"""
+    shard = getattr(plan, 'shard', None)
+    return shard if shard is not None and shard.world > 1 else None
+
+
+def entry_sum(x, plan):
+    """x = this rank's sum over (off-diagonal) entries -> the sum over every rank's entries"""
+    shard = shard_of(plan)
+    return x if shard is None else AllReduceSum.apply(x, shard)
+
+
 class SoftmaxPool(Function):
     """Per-graph softmax attention with a zeroth-order query: out[b] = sum_r softmax_r(q_b . k_r / sqrt(d)) v_r over the
     kept rows of graph b, per head.  Stands in for AttnCoef._vector_query + apply_attn(k = 0)
@@ -606,7 +635,11 @@ class SoftmaxPool(Function):
     softmax), so a single giant graph spreads over the chip."""
 
     @staticmethod
-    def forward(ctx, q, k, v, seg, kind, keep, H):
+    def forward(ctx, q, k, v, seg, kind, keep, H, shard=None):
+        """shard: edge-shard context when the pooled rows are ENTRIES spread over ranks (the rows of a rank are then pieces
+        of the graph's softmax like the pieces of a long segment: piece maxima MAX-all-reduced, the sums of exponentials and
+        the weighted piece outputs SUM-all-reduced; backward all-reduces the incoming gradient, since every rank's local
+        loss sees the replicated output)"""
         beg, end, _, maxlen = seg
         qs, ldq, nb, Cq = rows2d(q)
         ks, ldk, n, Ck = rows2d(k)
@@ -615,7 +648,7 @@ class SoftmaxPool(Function):
         d, c = Cq // H, Cv // H
         dev = q.device
         alpha = torch.zeros(n, H, dtype=q.dtype, device=dev)
-        split = maxlen > POOL_SPLIT
+        split = maxlen > POOL_SPLIT or shard is not None
         if not split:
             out = torch.empty(nb, Cv, dtype=q.dtype, device=dev)
             call('hotk_seg_softmax_pool_fwd', 4 * n * (Ck + Cv), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(beg), p(end), p(kind),
@@ -635,10 +668,16 @@ class SoftmaxPool(Function):
             m_p, s_p = stats[..., 0], stats[..., 1]
             M = torch.full((nb, H), float('-inf'), dtype=q.dtype, device=dev).scatter_reduce(
                 0, own.unsqueeze(1).expand(-1, H), m_p, 'amax', include_self=True)
+            if shard is not None:
+                shard.all_reduce_max_(M)
             w = torch.where(s_p > 0, s_p * torch.exp(m_p - M[own]), torch.zeros_like(s_p))
             Z = seg_sum_rows(w, group)
+            if shard is not None:
+                shard.all_reduce_(Z)
             wn = torch.where(Z[own] > 0, w / Z[own], torch.zeros_like(w))                       # [pieces, H]
             out = seg_sum_rows((outp.view(npc, H, c) * wn.unsqueeze(-1)).view(npc, Cv), group)
+            if shard is not None:
+                shard.all_reduce_(out)
             # alpha of a row = its within-piece softmax weight x the weight of its piece
             piece_of_row = torch.repeat_interleave(torch.arange(npc, device=dev), (fe - fb).long())
             row_ids = _piece_rows(fb, fe)
@@ -646,6 +685,7 @@ class SoftmaxPool(Function):
         ctx.save_for_backward(qs, ks, vs, alpha, out, beg, end)
         ctx.cfg = (ldq, ldk, ldv, nb, n, H, d, c, q.shape, k.shape, v.shape)
         ctx.split = (fine, group, owner) if split else None
+        ctx.shard = shard
         return out
 
     @staticmethod
@@ -653,6 +693,8 @@ class SoftmaxPool(Function):
         qs, ks, vs, alpha, out, beg, end = ctx.saved_tensors
         ldq, ldk, ldv, nb, n, H, d, c, qshape, kshape, vshape = ctx.cfg
         g = g.contiguous()
+        if ctx.shard is not None:
+            g = ctx.shard.all_reduce_(g.clone())
         dk = torch.zeros(n, H * d, dtype=g.dtype, device=g.device)
         dv = torch.zeros(n, H * c, dtype=g.dtype, device=g.device)
         if ctx.split is None:
@@ -666,7 +708,7 @@ class SoftmaxPool(Function):
             call('hotk_seg_softmax_pool_bwd', 4 * n * 2 * H * (d + c), p(qs), ldq, p(ks), ldk, p(vs), ldv, p(fine[0]), p(fine[1]),
                  p(alpha), p(out), H * c, p(g), H * c, p(dqp), H * d, p(dk), H * d, p(dv), H * c, p(owner), npc, H, d, c)
             dq = seg_sum_rows(dqp, group)
-        return dq.view(qshape), dk.view(kshape), dv.view(vshape), None, None, None, None
+        return dq.view(qshape), dk.view(kshape), dv.view(vshape), None, None, None, None, None
 
 
 def _piece_rows(fb, fe):

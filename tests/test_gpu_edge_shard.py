@@ -96,22 +96,90 @@ def _worker(rank, world, port, q, fused, generalized=True):
                'y': _rel(ys.values[0].detach(), ref_y[rows]),
                'gx_edges_bad_rows': bad_e, 'gx_nodes_bad_rows': bad_n,
                'gp': max(_rel(p.grad, ref_gp[k]) for k, p in layer2.named_parameters())}
-        # ops whose entry sums are not exchanged yet must refuse to run on a sharded plan instead of returning a
-        # partial result
-        from hot_amd import _lib
-        from hot_amd.models.common import KernelFeatureMap
-        from hot_amd.models import sparse as ms
-        refused = 0
-        for make in (lambda: ms.Linear(2, 2, 32, 8, cfg='default'), lambda: ms.Linear(2, 0, 32, 8, cfg='light'),
-                     lambda: ms.SelfAttn(2, 0, 32, 32, 32, 4)):
-            try:
-                make().to(DEV)(Gs)
-            except _lib.HotkError as exc:
-                refused += 'edge-shard' in str(exc)
-        res['refused'] = refused
         q.put((rank, res))
         ok = True
     except Exception as exc:                                       # report instead of leaving the parent to time out
+        import traceback
+        q.put((rank, {'error': repr(exc), 'trace': traceback.format_exc()}))
+    finally:
+        if ok:
+            dist.barrier()
+        dist.destroy_process_group()
+
+
+def _worker_models(rank, world, port, q):
+    """Linear(cfg='default') of every order, the graph-level pools and a whole Encoder(2, 0, ...) with its softmax readout
+    on a sharded graph, each against the CPU oracle on the whole graph.  Replicated outputs (order 1 / order 0) enter the
+    local loss with weight 1 / world, local order-2 rows with ShardInfo.entry_weight."""
+    import datetime
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+    ok = False
+    try:
+        torch.cuda.set_device(0)
+        from oracle import hot_oracle as O
+        from hot_amd.batch import sparse as bs
+        from hot_amd.dist import shard_graph, allreduce_gradients
+        from hot_amd.models import sparse as ms
+        from hot_amd.models.encoder import Encoder
+        nf, ei, ef, g = _graph(seed=11, n=120, n_pairs=420)
+        n, E = nf.size(0), ei.size(1)
+        GO = O.build_batch(nf, ei, ef, [n], [E])
+        Gs, own = shard_graph(nf.to(DEV), ei.to(DEV), ef.to(DEV), world, rank)
+        rows = torch.cat([torch.arange(n, device=DEV), n + own])
+        w_rows = Gs.plan.shard.entry_weight.view(-1, 1)
+        res = {'n_local_edges': int(own.numel())}
+
+        def check(tag, module, oracle_fn, out_order):
+            module = module.to(DEV)
+            sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
+                  for k, v in module.state_dict().items()}
+            xo = GO.values.clone().requires_grad_(True)
+            yo = oracle_fn(GO.like(xo), sd)
+            yo = yo.values[0] if out_order > 0 else yo[0]
+            Rw = torch.randn(yo.shape, generator=g)
+            (yo * Rw).sum().backward()
+            xs = Gs.values.clone().requires_grad_(True)
+            ys = module(bs.batch_like(Gs, xs, skip_masking=True))
+            ys = ys.values[0] if out_order > 0 else ys[0]
+            if out_order == 2:
+                ref_y, wl = yo.detach().to(DEV)[rows], Rw.to(DEV)[rows] * w_rows
+            else:
+                ref_y, wl = yo.detach().to(DEV), Rw.to(DEV) / world
+            (ys * wl).sum().backward()
+            allreduce_gradients(module.parameters())
+            gx = xs.grad[0].clone()
+            gx_nodes = gx[:n].clone()
+            Gs.plan.shard.all_reduce_(gx_nodes)
+            ref_gx = xo.grad[0].to(DEV)
+            scale = ref_gx.abs().max()
+            gscale = max(float(sd[k].grad.abs().max()) for k, _ in module.named_parameters())
+            res[tag] = {
+                'y': _rel(ys.detach(), ref_y),
+                'gx_edges_bad_rows': float((((gx[n:] - ref_gx[n + own]).abs().amax(-1) / scale) > 2e-5).float().mean()),
+                'gx_nodes_bad_rows': float((((gx_nodes - ref_gx[:n]).abs().amax(-1) / scale) > 2e-5).float().mean()),
+                'gp': max(float((p.grad.cpu() - sd[k].grad).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3 * gscale)
+                          for k, p in module.named_parameters())}
+
+        torch.manual_seed(0)
+        for normalize in (True, False):
+            t = 'n' if normalize else 'u'
+            check(f'lin22_default_{t}', ms.Linear(2, 2, 32, 24, cfg='default', normalize=normalize),
+                  lambda G, sd, nz=normalize: O.linear_forward(G, 2, 2, sd['weight.weight'],
+                                                               [sd['bias.bias.0'], sd['bias.bias.1']], 'default', nz), 2)
+            check(f'lin21_default_{t}', ms.Linear(2, 1, 32, 24, cfg='default', normalize=normalize),
+                  lambda G, sd, nz=normalize: O.linear_forward(G, 2, 1, sd['weight.weight'], [sd['bias.bias.0']], 'default', nz), 1)
+            check(f'lin20_{t}', ms.Linear(2, 0, 32, 24, cfg='light', normalize=normalize),
+                  lambda G, sd, nz=normalize: O.linear_forward(G, 2, 0, sd['weight.weight'], [sd['bias.bias.0']], 'light', nz), 0)
+        enc = Encoder(2, 0, [2], 32, 8, 32, 32, 32, 32, 4, 32, 32, 4, 'default', 'generalized_kernel', 0., 0., 0., sparse=True)
+        enc.skip_redraw_projections = True
+        enc.eval()
+        check('encoder_2_0', enc, lambda G, sd: O.encoder_2_0(G, sd, 1, 32, 32, 32, 32, 4, 32, 32, 4, True), 0)
+        q.put((rank, res))
+        ok = True
+    except Exception as exc:
         import traceback
         q.put((rank, {'error': repr(exc), 'trace': traceback.format_exc()}))
     finally:
@@ -157,7 +225,44 @@ def test_edge_shard_matches_oracle_on_whole_graph(world, fused, generalized):
     for rank, r in results.items():
         assert r['y'] < 1e-5, (rank, r)
         assert r['gx_edges_bad_rows'] <= 5e-3 and r['gx_nodes_bad_rows'] <= 5e-3 and r['gp'] < 1e-3, (rank, r)
-        assert r['refused'] == 3, (rank, r)
+
+
+def _run_ranks(target, world, extra=()):
+    import torch.multiprocessing as mp
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra), daemon=True) for r in range(world)]
+    for p in procs:
+        p.start()
+    try:
+        results = dict(q.get(timeout=200) for _ in range(world))
+        for p in procs:
+            p.join(timeout=60)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=10)
+    errors = {r: v for r, v in results.items() if 'error' in v}
+    assert not errors, errors
+    assert all(p.exitcode == 0 for p in procs)
+    return results
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_edge_shard_default_basis_pools_and_readout_match_oracle(world):
+    """the sums over entries outside the attention core in edge-shard mode: row / column / graph pools of
+    Linear(cfg='default') (models/sparse/linear.py:85-238) and their element counts, the order-2 -> order-0 pool, and the
+    softmax readout of Encoder(2, 0, ...) (sparse/attn.py:112-131, attncoef.py:25-59) -- all-reduced sums, MAX-reduced
+    softmax stabiliser -- against the oracle on the whole graph"""
+    results = _run_ranks(_worker_models, world)
+    print('edge-shard model results', results)
+    for rank, r in results.items():
+        assert r.pop('n_local_edges') > 0
+        for tag, v in r.items():
+            assert v['y'] < 1e-5, (rank, tag, v)
+            assert v['gx_edges_bad_rows'] <= 5e-3 and v['gx_nodes_bad_rows'] <= 5e-3 and v['gp'] < 1e-3, (rank, tag, v)
 
 
 def test_fused_phases_single_rank_equal_one_pass():
