@@ -73,8 +73,8 @@ def plan_node_graph(plan):
 
 
 def _plan_counts(plan, n_nodes, n_edges):
-    """Per-node / per-entry element counts of every pool (integer bookkeeping from the CSR pointers, cached on the
-    plan): od/idg = off-diagonal out/in degree per node row, n / Eo per graph, and their gathers to entry rows."""
+    """Element counts of every pool (integer bookkeeping from the CSR pointers, cached on the plan): od / idg =
+    off-diagonal out / in degree per node row, n / Eo per graph and their gathers to node rows (fp32)."""
     if not hasattr(plan, '_counts'):
         dev = plan.device
         f = dict(dtype=torch.float32, device=dev)
@@ -88,11 +88,8 @@ def _plan_counts(plan, n_nodes, n_edges):
         n_g = torch.as_tensor(n_nodes, **f).unsqueeze(1)                            # [B,1]
         eo_g = offdiag_count(plan, n_nodes, n_edges, torch.float32, dev)
         ng = plan_node_graph(plan).long()
-        eg = plan_entry_graph(plan).long()
-        ri, ci = plan.rown.clamp(min=0).long(), plan.coln.clamp(min=0).long()
-        tau = (plan.tpos >= 0).to(torch.float32).unsqueeze(1) * (plan.kind == 2).to(torch.float32).unsqueeze(1)
-        plan._counts = dict(od=od, idg=idg, n_node=n_g[ng], eo_node=eo_g[ng], n_entry=n_g[eg], eo_entry=eo_g[eg],
-                            odi=od[ri], odj=od[ci], idi=idg[ri], idj=idg[ci], tau=tau)
+        plan._counts = dict(od=od.contiguous(), idg=idg.contiguous(), n_graph=n_g.contiguous(), eo_graph=eo_g.contiguous(),
+                            n_node=n_g[ng], eo_node=eo_g[ng])
     return plan._counts
 
 
@@ -157,37 +154,9 @@ def basis_2_to_1(G, dG, normalize):
 
 def basis_2_to_2(G, normalize):
     """The 15 order-2 -> order-2 basis tensors (linear.py:143-238) in closed form from the row / column /
-    graph segment sums: O(E) instead of the reference's [B,E,E] masks.  Gathers and segment sums are HIP kernels
-    (hotk_gather_rows / hotk_seg_sum_rows / hotk_mask_rows); the closed-form combination is elementwise."""
+    graph segment sums: O(E) instead of the reference's [B,E,E] masks; one expand kernel (ops.Basis22Full)."""
     plan = G.plan
     c = _plan_counts(plan, G.n_nodes, G.n_edges)
-    A, diag, R, C, T, S = _order2_sums(G)
-    off = lambda X: ops.MaskRows.apply(X, plan.kind, KEEP_OFFDIAG, 0.0)
-    to_d = lambda Xn: ops.GatherRows.apply(Xn, plan.diag_node, plan.diag_pos, plan.R)
-    rows, cols = plan.row_seg(), plan.col_seg()
-    by_i = lambda Xn: ops.GatherSeg.apply(Xn, plan.rown, rows, plan.R)
-    by_j = lambda Xn: ops.GatherSeg.apply(Xn, plan.coln, cols, plan.R)
-    ng, eg = plan_node_graph(plan), plan_entry_graph(plan)
-    nm = (plan.nkind == 1).to(A.dtype).unsqueeze(1)
-    At = ops.GatherRows.apply(A, plan.tpos, plan.tpos, plan.R)
-    Aii, Ajj = by_i(diag), by_j(diag)
-    V = [ops.MaskRows.apply(A, plan.kind, KEEP_DIAG, 0.0), off(A), off(At), off(Aii), off(Ajj)]
-    Tn = ops.GatherSeg.apply(T, ng, plan.graph_seg(1), plan.Nn)
-    Sn = ops.GatherSeg.apply(S, ng, plan.graph_seg(1), plan.Nn)
-    V6 = to_d(_nrm(R, c['od'], normalize) * nm)
-    V7 = to_d(_nrm(C, c['idg'], normalize) * nm)
-    V12 = to_d(_nrm(Tn - diag, c['n_node'] - 1, normalize) * nm)
-    V13 = to_d(_nrm(Sn - R - C, c['eo_node'] - c['od'] - c['idg'], normalize) * nm)
-    Ri, Rj, Ci, Cj = by_i(R), by_j(R), by_i(C), by_j(C)
-    Te = ops.GatherSeg.apply(T, eg, plan.graph_seg(2), plan.R)
-    Se = ops.GatherSeg.apply(S, eg, plan.graph_seg(2), plan.R)
-    tau = c['tau']
-    V8 = off(_nrm(Cj - A, c['idj'] - 1, normalize))
-    V9 = off(_nrm(Ri - A, c['odi'] - 1, normalize))
-    V10 = off(_nrm(Rj - At, c['odj'] - tau, normalize))
-    V11 = off(_nrm(Ci - At, c['idi'] - tau, normalize))
-    V14 = off(_nrm(Te - Aii - Ajj, c['n_entry'] - 2, normalize))
-    V15 = off(_nrm(Se - Ri - Ci - Rj - Cj + A + At,
-                   c['eo_entry'] - c['odi'] - c['idi'] - c['odj'] - c['idj'] + 1 + tau, normalize))
-    V += [V6, V7, V8, V9, V10, V11, V12, V13, V14, V15]
-    return torch.cat(V, -1).view(plan.B, plan.Emax, -1)
+    counts = (c['od'].view(-1), c['idg'].view(-1), c['n_graph'].view(-1), c['eo_graph'].view(-1))
+    V = ops.Basis22Full.apply(G.values.reshape(plan.R, -1), plan, counts, bool(normalize))
+    return V.view(plan.B, plan.Emax, -1)

@@ -397,6 +397,67 @@ class Basis22Light(Function):
         return dx, None
 
 
+class Basis22Full(Function):
+    """V = the 15 order-2 -> order-2 basis tensors of Linear(2, 2, cfg='default') concatenated, [R, 15 D]
+    (models/sparse/linear.py:143-238), from closed forms of the per-node / per-graph sums: hotk_basis22_full_fwd after
+    five segment sums / gathers; the backward is the transpose map (hotk_basis22_full_bwd_entries, three segment sums,
+    hotk_basis22_full_bwd_gather).  counts = (od, idg [Nn], n_graph, eo_graph [B]) as fp32.  Edge-shard mode: the
+    off-diagonal row / column / graph sums and their gradients are all-reduced (the diagonal is replicated)."""
+
+    @staticmethod
+    def _entry_sums(nt, gt, D, shard):
+        """all-reduce of the sums over off-diagonal entries inside the node / graph tables (in place)"""
+        if shard is None:
+            return
+        flat = torch.cat([nt[:, D:].reshape(-1), gt[:, D:].reshape(-1)])
+        shard.all_reduce_(flat)
+        k = nt.size(0) * 2 * D
+        nt[:, D:] = flat[:k].view(-1, 2 * D)
+        gt[:, D:] = flat[k:].view(-1, D)
+
+    @staticmethod
+    def forward(ctx, x, plan, counts, normalize):
+        xs, ld, n, D = rows2d(x)
+        assert n == plan.R and xs.dtype == torch.float32
+        _lib.require_device(xs)
+        dev = xs.device
+        od, idg, ng, eog = counts
+        nt = torch.empty(plan.Nn, 3 * D, dtype=torch.float32, device=dev)
+        gt = torch.empty(plan.B, 2 * D, dtype=torch.float32, device=dev)
+        gather_rows(xs, plan.diag_pos, plan.Nn, out=nt[:, 0:D])
+        seg_sum_rows(xs, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=nt[:, D:2 * D])
+        seg_sum_rows(xs, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=nt[:, 2 * D:])
+        seg_sum_rows(xs, plan.graph_seg(2), plan.kind, KEEP_DIAG, out=gt[:, 0:D])
+        seg_sum_rows(xs, plan.graph_seg(2), plan.kind, KEEP_OFFDIAG, out=gt[:, D:])
+        shard = shard_of(plan)
+        Basis22Full._entry_sums(nt, gt, D, shard)
+        V = torch.empty(n, 15 * D, dtype=torch.float32, device=dev)
+        call('hotk_basis22_full_fwd', 4 * n * (2 * D + 15 * D), p(xs), ld, p(plan.kind), p(plan.rown), p(plan.coln),
+             p(plan.tpos), p(nt), 3 * D, p(gt), 2 * D, p(od), p(idg), p(ng), p(eog), p(V), 15 * D, n, D, max(plan.Emax, 1),
+             int(normalize))
+        ctx.plan, ctx.counts, ctx.normalize, ctx.xshape, ctx.shard = plan, counts, int(normalize), x.shape, shard
+        return V.view(*x.shape[:-1], 15 * D)
+
+    @staticmethod
+    def backward(ctx, g):
+        plan, (od, idg, ng, eog) = ctx.plan, ctx.counts
+        D = ctx.xshape[-1]
+        n = plan.R
+        g = g.contiguous().view(n, 15 * D)
+        dev = g.device
+        w = torch.empty(n, 10 * D, dtype=torch.float32, device=dev)
+        call('hotk_basis22_full_bwd_entries', 4 * n * 25 * D, p(g), 15 * D, p(plan.kind), p(plan.rown), p(plan.coln),
+             p(plan.tpos), p(od), p(idg), p(ng), p(eog), p(w), 10 * D, n, D, max(plan.Emax, 1), ctx.normalize)
+        dn = seg_sum_rows(w[:, 2 * D:5 * D], plan.row_seg(), plan.kind, KEEP_VALID)
+        dn += seg_sum_rows(w[:, 5 * D:8 * D], plan.col_seg(), plan.kind, KEEP_OFFDIAG)
+        dg = seg_sum_rows(w[:, 8 * D:], plan.graph_seg(2), plan.kind, KEEP_VALID)
+        Basis22Full._entry_sums(dn, dg, D, ctx.shard)      # gradients of the all-reduced sums
+        dx = torch.empty(n, D, dtype=torch.float32, device=dev)
+        call('hotk_basis22_full_bwd_gather', 4 * n * 4 * D, p(w), 10 * D, p(plan.kind), p(plan.rown), p(plan.coln),
+             p(plan.tpos), p(dn), 3 * D, p(dg), 2 * D, p(dx), D, n, D, max(plan.Emax, 1))
+        return dx.view(ctx.xshape), None, None, None
+
+
 class Linear22Light(Function):
     """y = Linear(2, 2, cfg='light')(x) incl. both biases and the padding mask, in factored form.
 

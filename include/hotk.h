@@ -129,6 +129,29 @@ int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind,
 int hotk_assemble22(float* z, int64_t ld, const float* yn, int64_t ld_yn, const uint8_t* kind, const int32_t* rown,
                     const int32_t* coln, const float* b_off, const float* b_diag, int64_t R, int64_t C, void* stream);
 
+/* The full 15-operator order-2 -> order-2 basis of Linear(2, 2, cfg='default') (models/sparse/linear.py:143-238; the
+ * reference pools with [B,E,E] boolean masks and bmm's, O(E^2)) as one expand kernel over closed forms of per-node and
+ * per-graph sums:  out[r] = [V1 | ... | V15]  ([R, 15 D], the reference's block order).
+ *   node_tab  [Nn, 3 D] = A_vv | off-diagonal row sum | off-diagonal column sum      (hotk_gather_rows / hotk_seg_sum_rows)
+ *   graph_tab [B, 2 D]  = trace | off-diagonal total;   od / idg [Nn], n_graph / eo_graph [B]: element counts as floats
+ *   normalize: every pooled operator divided by its element count, a pool over an empty set is 0 (linear.py:162-238).
+ * Transpose map (the basis is linear in the values, nothing is saved): _bwd_entries turns the gradient g [R, 15 D] into
+ *   w [R, 10 D] = [ own | transposed partner's | row node: d diag, d rowsum, d colsum | column node: same | d trace, d total ];
+ * the caller sums w[:, 2D:5D] per row node, w[:, 5D:8D] per column node and w[:, 8D:10D] per graph (hotk_seg_sum_rows) into
+ * dnode [Nn, 3 D] / dgraph [B, 2 D]; _bwd_gather finishes dx [R, D]. */
+int hotk_basis22_full_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
+                          const int32_t* tpos, const float* node_tab, int64_t ld_nt, const float* graph_tab, int64_t ld_gt,
+                          const float* od, const float* idg, const float* n_graph, const float* eo_graph, float* out,
+                          int64_t ld_out, int64_t R, int64_t D, int64_t Emax, int normalize, void* stream);
+int hotk_basis22_full_bwd_entries(const float* g, int64_t ld_g, const uint8_t* kind, const int32_t* rown,
+                                  const int32_t* coln, const int32_t* tpos, const float* od, const float* idg,
+                                  const float* n_graph, const float* eo_graph, float* w, int64_t ld_w, int64_t R,
+                                  int64_t D, int64_t Emax, int normalize, void* stream);
+int hotk_basis22_full_bwd_gather(const float* w, int64_t ld_w, const uint8_t* kind, const int32_t* rown,
+                                 const int32_t* coln, const int32_t* tpos, const float* dnode, int64_t ld_dn,
+                                 const float* dgraph, int64_t ld_dg, float* dx, int64_t ld_dx, int64_t R, int64_t D,
+                                 int64_t Emax, void* stream);
+
 /* Thin GEMMs of the dense projections with the weight resident in LDS (fp32 MFMA) and the row epilogue fused:
  *   Y[R, C] = A[R, K] @ W[K, C] (+ bias[C]) (+ res[R, C])        W row-major [K, C]
  * stands in for nn.Linear / `V @ weight` and their data gradients over the ~1e7 entry rows of a batch
