@@ -34,7 +34,7 @@ _SIGNATURES = {
     'hotk_basis22_light_fwd': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_basis22_light_bwd': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_basis22_pair_fwd': [_P, _L, _P, _P, _P, _L, _L, _L, _P],
-    'hotk_basis22_pair_bwd': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _L, _L, _P],
+    'hotk_basis22_pair_bwd': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _P],
     'hotk_assemble22': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_basis22_full_fwd': [_P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P],
     'hotk_basis22_full_bwd_entries': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P],

@@ -299,12 +299,13 @@ __global__ void k_basis22_pair_fwd(const float* __restrict__ x, int64_t ld_x, co
   }
 }
 
-// transpose map of k_basis22_pair_fwd plus the node-level gradient on the diagonal rows
+// transpose map of k_basis22_pair_fwd plus the node-level gradient on the diagonal rows; add (optional, [R, D]): another
+// gradient of the same input, added on valid rows (one pass instead of a separate elementwise sum over [R, D])
 template <int V>
 __global__ void k_basis22_pair_bwd(const float* __restrict__ g, int64_t ld_g, const uint8_t* __restrict__ kind,
                                    const int32_t* __restrict__ tpos, const int32_t* __restrict__ rown,
-                                   const float* __restrict__ gd, int64_t ld_gd, float* __restrict__ dx, int64_t ld_dx,
-                                   int64_t R, int64_t D) {
+                                   const float* __restrict__ gd, int64_t ld_gd, const float* __restrict__ add,
+                                   int64_t ld_add, float* __restrict__ dx, int64_t ld_dx, int64_t R, int64_t D) {
   using T = typename VecT<V>::type;
   const int64_t DV = D / V, total = R * DV;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -318,6 +319,7 @@ __global__ void k_basis22_pair_bwd(const float* __restrict__ g, int64_t ld_g, co
     } else if (kd == 1) {
       acc = *reinterpret_cast<const T*>(gd + (int64_t)rown[r] * ld_gd + c);
     }
+    if (add && kd) acc = vadd(acc, *reinterpret_cast<const T*>(add + r * ld_add + c));
     *reinterpret_cast<T*>(dx + r * ld_dx + c) = acc;
   }
 }
@@ -543,18 +545,18 @@ extern "C" int hotk_basis22_pair_fwd(const float* x, int64_t ld_x, const uint8_t
 }
 
 extern "C" int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind, const int32_t* tpos,
-                                     const int32_t* rown, const float* dxd, int64_t ld_dxd, float* dx, int64_t ld_dx,
-                                     int64_t R, int64_t D, void* stream) {
-  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_dx >= D && ld_dx2 >= 2 * D && ld_dxd >= D);
+                                     const int32_t* rown, const float* dxd, int64_t ld_dxd, const float* add,
+                                     int64_t ld_add, float* dx, int64_t ld_dx, int64_t R, int64_t D, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_dx >= D && ld_dx2 >= 2 * D && ld_dxd >= D && (!add || ld_add >= D));
   if (R == 0 || D == 0) return HOTK_OK;
   HOTK_CHECK_ARG(dx2 && kind && tpos && rown && dxd && dx);
   hipStream_t st = (hipStream_t)stream;
-  if (vec4_ok(D, {ld_dx2, ld_dxd, ld_dx}, {dx2, dxd, dx})) {
+  if (vec4_ok(D, {ld_dx2, ld_dxd, ld_dx, add ? ld_add : 0}, {dx2, dxd, dx, add})) {
     hipLaunchKernelGGL(k_basis22_pair_bwd<4>, dim3(hotk_grid(R * (D / 4), 256)), dim3(256), 0, st, dx2, ld_dx2, kind, tpos,
-                       rown, dxd, ld_dxd, dx, ld_dx, R, D);
+                       rown, dxd, ld_dxd, add, ld_add, dx, ld_dx, R, D);
   } else {
     hipLaunchKernelGGL(k_basis22_pair_bwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, dx2, ld_dx2, kind, tpos, rown,
-                       dxd, ld_dxd, dx, ld_dx, R, D);
+                       dxd, ld_dxd, add, ld_add, dx, ld_dx, R, D);
   }
   return hotk_launch_status();
 }

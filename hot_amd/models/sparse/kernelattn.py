@@ -124,8 +124,21 @@ class KernelSelfAttn(nn.Module):
                 and self.dim_qk == 32 and self.dim_v == 32 and self.feat_dim == 16)
 
     def _2_to_2(self, G: B):
+        sharded = getattr(G.plan, 'shard', None) is not None     # (edge-shard mode runs the fp32 core in phases)
+        if self._fused_ok() and (self.storage == 'f32' or sharded):
+            # the three input projections as one autograd node (the layer input's gradient is written once), then the
+            # fused core with fc_o; padding rows are ignored by the kernels: no masking pass
+            b1 = self.fc_1.bias.bias[0] if hasattr(self.fc_1, 'bias') else None
+            b2 = self.fc_2.bias.bias if hasattr(self.fc_2, 'bias') else (None, None)
+            h_1, h_2, v = ops.Proj22.apply(G.values, self.fc_1.weight.weight, b1, self.fc_2.weight.weight, b2[0], b2[1],
+                                           self.fc_v.weight, self.fc_v.bias, G.plan, sum(G.n_nodes) != G.plan.Nn)
+            drop_p = self.dropout.p if self.training else 0.
+            mu_p = self.mu_dropout.p if self.training else 0.
+            out = ops.AttnCore22.apply(h_1, h_2, v, self.feature_map.feature_map.projection_matrix,
+                                       self.fc_o.weight, self.fc_o.bias, G.plan, drop_p, mu_p)
+            return batch_like(G, out, skip_masking=True)
         h_1 = self.fc_1(G)                      # [B, N, 12 dqk]: 4 query slots, 8 key slots
-        if self.storage == 'bf16' and self._fused_ok() and getattr(G.plan, 'shard', None) is None:
+        if self.storage == 'bf16' and self._fused_ok():
             drop_p = self.dropout.p if self.training else 0.
             mu_p = self.mu_dropout.p if self.training else 0.
             fb = self.fc_2.bias.bias if hasattr(self.fc_2, 'bias') else (None, None)
@@ -134,14 +147,6 @@ class KernelSelfAttn(nn.Module):
                                             self.feature_map.feature_map.projection_matrix, G.plan, drop_p, mu_p)
             return batch_like(G, out, skip_masking=True)
         h_2 = self.fc_2(G)                      # [B, |E|, 8 dqk + D]: 6 query slots, 2 key slots, skip path
-        if self._fused_ok():   # (edge-shard mode: ops.AttnCore22 runs the core in phases with all-reduces in between)
-            # padding rows are ignored by the kernels: no masking pass
-            v = ops.RowsMatmul.apply(G.values, self.fc_v.weight.t(), self.fc_v.bias)   # [R, 10 dv]
-            drop_p = self.dropout.p if self.training else 0.
-            mu_p = self.mu_dropout.p if self.training else 0.
-            out = ops.AttnCore22.apply(h_1.values, h_2.values, v, self.feature_map.feature_map.projection_matrix,
-                                       self.fc_o.weight, self.fc_o.bias, G.plan, drop_p, mu_p)
-            return batch_like(G, out, skip_masking=True)
         non_att = batch_like(h_2, h_2.values[..., -self.dim_in:], skip_masking=True)
         q_1 = self._phi_slots(h_1, 0, 4, True)
         k_1 = self._phi_slots(h_1, 4, 12, False)

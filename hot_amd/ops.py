@@ -458,6 +458,61 @@ class Basis22Full(Function):
         return dx.view(ctx.xshape), None, None, None
 
 
+def _l22_forward(xs, ld, W, b_off, b_diag, plan):
+    """factored Linear(2, 2, 'light') on rows xs [R, D] -> (y [R, C], xd [Nn, D], x2 [R, 2D])"""
+    n, D = plan.R, W.size(0) // 5
+    C = W.size(1)
+    dev = xs.device
+    xd = gather_rows(xs, plan.diag_pos, plan.Nn)                                   # [Nn, D]
+    Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)               # [D, 3C]
+    yn = xd @ Wn
+    x2 = torch.empty(plan.R, 2 * D, dtype=xs.dtype, device=dev)
+    call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
+    if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
+        # entry GEMM with the assembly as its epilogue: y is written once
+        y = torch.empty(n, C, dtype=xs.dtype, device=dev)
+        call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
+             p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
+    else:
+        y = x2 @ W[D:3 * D]
+        call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
+             p(b_diag), n, C)
+    return y, xd, x2
+
+
+def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_extra=None, dx_add=None):
+    """gradients of the factored Linear(2, 2, 'light') from g = dy [R, C] -> (dx [R, D], dW [5D, C], db_off, db_diag).
+    dxd_extra [Nn, D]: another gradient of the diagonal input rows (fc_1's), dx_add [R, D]: another gradient of all input
+    rows (fc_v's); both are folded into hotk_basis22_pair_bwd's single pass over dx."""
+    D, C = xd.size(1), W.size(1)
+    dev = g.device
+    if plan.Ev != plan.R:
+        g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)      # padding rows of an upstream gradient may hold anything
+    # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
+    dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
+    call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
+    seg_sum_rows(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
+    seg_sum_rows(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
+    # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
+    # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows
+    db_diag = dyn[:, 0:C].sum(0) if has_b[1] else None
+    db_off = dyn[:, C:2 * C].sum(0) if has_b[0] else None
+    Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
+    dx = dW = None
+    if want_dx:
+        dxd = dyn @ Wn.t()
+        if dxd_extra is not None:
+            dxd += dxd_extra
+        dx2 = g @ W[D:3 * D].t()      # plain products stay library GEMMs: measured on par with the thin kernel
+        dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
+        call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
+             p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
+    if want_dw:
+        dWn = wgrad(xd, dyn)
+        dW = torch.cat([dWn[:, 0:C], wgrad(x2, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
+    return dx, dW, db_off, db_diag
+
+
 class Linear22Light(Function):
     """y = Linear(2, 2, cfg='light')(x) incl. both biases and the padding mask, in factored form.
 
@@ -471,57 +526,67 @@ class Linear22Light(Function):
     def forward(ctx, x, W, b_off, b_diag, plan):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R and W.size(0) == 5 * D
-        C = W.size(1)
-        dev = x.device
-        xd = gather_rows(xs, plan.diag_pos, plan.Nn)                                   # [Nn, D]
-        Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)               # [D, 3C]
-        yn = xd @ Wn
-        x2 = torch.empty(plan.R, 2 * D, dtype=x.dtype, device=dev)
-        call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
-        if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
-            # entry GEMM with the assembly as its epilogue: y is written once
-            y = torch.empty(n, C, dtype=x.dtype, device=dev)
-            call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
-                 p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
-        else:
-            y = x2 @ W[D:3 * D]
-            call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
-                 p(b_diag), n, C)
+        y, xd, x2 = _l22_forward(xs, ld, W, b_off, b_diag, plan)
         ctx.save_for_backward(xd, x2, W)
         ctx.plan, ctx.has_b, ctx.xshape = plan, (b_off is not None, b_diag is not None), x.shape
-        return y.view(*x.shape[:-1], C)
+        return y.view(*x.shape[:-1], W.size(1))
 
     @staticmethod
     def backward(ctx, g):
         xd, x2, W = ctx.saved_tensors
         plan = ctx.plan
-        D, C = xd.size(1), W.size(1)
-        dev = g.device
-        g = g.contiguous().view(plan.R, C)
-        if plan.Ev != plan.R:
-            g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)      # padding rows of an upstream gradient may hold anything
-        # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
-        dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
-        call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-        seg_sum_rows(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
-        seg_sum_rows(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
-        # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
-        # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows
-        db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
-        db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
-        Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
-        dx = dW = None
-        if ctx.needs_input_grad[0]:
-            dxd = dyn @ Wn.t()
-            dx2 = g @ W[D:3 * D].t()      # plain products stay library GEMMs: measured on par with the thin kernel
-            dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
-            call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
-                 p(dxd), D, p(dx), D, plan.R, D)
-            dx = dx.view(ctx.xshape)
-        if ctx.needs_input_grad[1]:
-            dWn = wgrad(xd, dyn)
-            dW = torch.cat([dWn[:, 0:C], wgrad(x2, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
-        return dx, dW, db_off, db_diag, None
+        g = g.contiguous().view(plan.R, W.size(1))
+        dx, dW, db_off, db_diag = _l22_backward(g, xd, x2, W, plan, ctx.has_b, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        return (None if dx is None else dx.view(ctx.xshape)), dW, db_off, db_diag, None
+
+
+class Proj22(Function):
+    """The three input projections of KernelSelfAttn(2, 2) (models/sparse/kernelattn.py:119-123: h_1 = fc_1(G),
+    h_2 = fc_2(G), v = fc_v(G.values)) as ONE autograd node: the layer input feeds all three, so autograd would
+    otherwise materialise three [R, D] gradients (one of them a scatter of the diagonal rows into zeros) and add them
+    in two more passes.  Here fc_1's node-level gradient joins fc_2's before hotk_basis22_pair_bwd and fc_v's is added
+    inside that kernel: dx is written once.  Forward is the same kernels as Linear(2,1,'light') (diagonal gather + GEMM
+    + bias / padding mask), ops.Linear22Light and ops.RowsMatmul."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2_off, b2_diag, Wv, bv, plan, nodes_padded):
+        xs, ld, n, D = rows2d(x)
+        assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
+        h2, xd, x2 = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
+        h1 = xd @ W1
+        call('hotk_bias_mask_rows', 8 * plan.Nn * h1.size(1), p(h1), h1.size(1), p(plan.nkind), p(None), p(b1), plan.Nn,
+             h1.size(1))
+        xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
+        wv = Wv.t()
+        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else torch.addmm(bv, xc, wv)
+        ctx.save_for_backward(xc, xd, x2, W1, W2, Wv)
+        ctx.plan, ctx.xshape, ctx.nodes_padded = plan, x.shape, nodes_padded
+        ctx.has_b = (b1 is not None, b2_off is not None, b2_diag is not None)
+        return h1.view(plan.B, plan.Nmax, -1), h2.view(plan.B, plan.Emax, -1), v.view(plan.B, plan.Emax, -1)
+
+    @staticmethod
+    def backward(ctx, dh1, dh2, dv):
+        xc, xd, x2, W1, W2, Wv = ctx.saved_tensors
+        plan = ctx.plan
+        D = xc.size(1)
+        # fc_v: dx, dW and db from one pass over dv
+        dv2 = dv.contiguous().view(plan.R, -1)
+        wv = Wv.t()
+        if linear_bwd_ok(plan.R, D, dv2.size(1)):
+            dxv, dwv, dbv = linear_bwd_fused(dv2, xc, wv)
+        else:
+            dxv, dwv, dbv = dv2 @ Wv, wgrad(xc, dv2), dv2.sum(0)
+        # fc_1 (node rows)
+        g1 = dh1.contiguous().view(plan.Nn, -1)
+        if ctx.nodes_padded:
+            g1 = mask_rows(g1, plan.nkind, KEEP_VALID, 0.0)
+        db1 = bias_grads(g1, plan.nkind, False, True)[1] if ctx.has_b[0] else None
+        dW1 = wgrad(xd, g1)
+        dxd1 = g1 @ W1.t()
+        # fc_2, with the other two gradients of x folded in
+        g2 = dh2.contiguous().view(plan.R, -1)
+        dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv)
+        return dx.view(ctx.xshape), dW1, db1, dW2, db_off, db_diag, dwv.t(), dbv, None, None
 
 
 class Assemble12(Function):
@@ -1157,9 +1222,8 @@ class AttnLayer22BF16(Function):
         dxd = dyn @ Wn.t()
         dx2 = (g @ W2[D:3 * D].t().to(bf)).float()
         dx = torch.empty(R, D, dtype=torch.float32, device=dev)
-        call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D, p(dx),
-             D, R, D)
-        dx += dxv
+        call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D,
+             p(dxv.float()), D, p(dx), D, R, D)
         dWn = wgrad(xd, dyn)
         dW2 = torch.cat([dWn[:, 0:C], wgrad(x2b, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
         xshape, h1shape = ctx.shapes

@@ -120,12 +120,13 @@ int hotk_basis22_light_bwd(const float* dx5, int64_t ld_dx5, const uint8_t* kind
  * goes through the big GEMM z = x2 @ [W2; W3].  hotk_assemble22 finishes y in place on z:
  *   off-diagonal (i,j): z + yn[i][C..2C) + yn[j][2C..3C) + b_off;  diagonal (v,v): yn[v][0..C) + b_diag;  padding: 0
  * (models/sparse/linear.py:143-161 basis, :46-48 projection, :297-306 bias, :345-346 mask).  pair_bwd is the transpose
- * map: dx[r] = off-diagonal ? dx2[r][0..D) + (tau ? dx2[t(r)][D..2D) : 0) : diagonal ? dxd[node] : 0. */
+ * map: dx[r] = off-diagonal ? dx2[r][0..D) + (tau ? dx2[t(r)][D..2D) : 0) : diagonal ? dxd[node] : 0, plus add[r] on valid
+ * rows when add != NULL (another gradient of the same input -- fc_v's -- folded into the pass). */
 int hotk_basis22_pair_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
                           int64_t ld_x2, int64_t R, int64_t D, void* stream);
 int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind, const int32_t* tpos,
-                          const int32_t* rown, const float* dxd, int64_t ld_dxd, float* dx, int64_t ld_dx, int64_t R,
-                          int64_t D, void* stream);
+                          const int32_t* rown, const float* dxd, int64_t ld_dxd, const float* add, int64_t ld_add,
+                          float* dx, int64_t ld_dx, int64_t R, int64_t D, void* stream);
 int hotk_assemble22(float* z, int64_t ld, const float* yn, int64_t ld_yn, const uint8_t* kind, const int32_t* rown,
                     const int32_t* coln, const float* b_off, const float* b_diag, int64_t R, int64_t C, void* stream);
 

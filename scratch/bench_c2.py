@@ -25,9 +25,13 @@ G = make_batch_concatenated(nf, ei, ef, nn_, ne_)
 torch.manual_seed(0)
 enc = Encoder(2, 0, [2] * 8, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel', 0., 0., 0., sparse=True).to(dev)
 enc.skip_redraw_projections = True
+STORAGE = os.environ.get('HOTK_C2_STORAGE', 'f32')      # bf16: the fused 2->2 layers in their bf16 storage mode
+for lyr in enc.layers:
+    if hasattr(lyr.attn, 'set_storage'):
+        lyr.attn.set_storage(STORAGE)
 head = torch.nn.Linear(256, 1).to(dev)
 params = list(enc.parameters()) + list(head.parameters())
-print('graphs', B, 'entries', sum(G.n_edges), 'padded', G.values.shape[0] * G.values.shape[1], 'params %.2f M' % (sum(p.numel() for p in params) / 1e6))
+print('storage', STORAGE, 'graphs', B, 'entries', sum(G.n_edges), 'padded', G.values.shape[0] * G.values.shape[1], 'params %.2f M' % (sum(p.numel() for p in params) / 1e6))
 def step():
     y = head(enc(G)).squeeze(-1)
     loss = torch.nn.functional.l1_loss(y, torch.zeros_like(y))
