@@ -33,7 +33,7 @@ BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEAD
 # passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
 # profiles/r02_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at the benchmarked size (10 M entries; the
 # round-1 pass at 2 M entries gave 4903 / 8584: per-entry figures are size-independent)
-PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4886, 'hotk_attn22_backward': 8575}
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4886, 'hotk_attn22_backward': 8592}
 PMC_TRAFFIC_SOURCE = 'profiles/r02_pmc_traffic_attn22.txt'
 
 
