@@ -23,7 +23,10 @@ ei = torch.from_numpy(np.concatenate(eis, axis=1)).to(dev)
 nf = torch.randn(sum(nn_), 256, device=dev); ef = torch.randn(sum(ne_), 256, device=dev)
 G = make_batch_concatenated(nf, ei, ef, nn_, ne_)
 torch.manual_seed(0)
-enc = Encoder(2, 0, [2] * 8, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel', 0., 0., 0., sparse=True).to(dev)
+if os.environ.get('HOTK_C2_ARCH', 'enc-small') == 'enc':      # enc.sh: dim_hidden 512, dim_qk = dim_v = 64 (d = 16, m = 44)
+    enc = Encoder(2, 0, [2] * 8, 512, 256, 512, 64, 64, 512, 4, 256, 256, 16, 'default', 'generalized_kernel', 0., 0., 0., sparse=True).to(dev)
+else:
+    enc = Encoder(2, 0, [2] * 8, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel', 0., 0., 0., sparse=True).to(dev)
 enc.skip_redraw_projections = True
 STORAGE = os.environ.get('HOTK_C2_STORAGE', 'f32')      # bf16: the fused 2->2 layers in their bf16 storage mode
 for lyr in enc.layers:

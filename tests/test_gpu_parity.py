@@ -433,8 +433,9 @@ def _ba_case(n_graphs, seed):
     return nfs, eis, efs, g
 
 
-@pytest.mark.parametrize('generalized,fused', [(False, False), (True, False), (True, True)])
-def test_layer_vs_oracle_ba_graphs(generalized, fused):
+@pytest.mark.parametrize('generalized,fused,dqk', [(False, False, 32), (True, False, 32), (True, True, 32),
+                                                   (True, False, 64), (False, False, 64)])
+def test_layer_vs_oracle_ba_graphs(generalized, fused, dqk):
     """C1-shaped workload (BA(64,5) graphs, D = dqk = dv = 32, 4 heads) at a size the oracle runs in seconds.
 
     Softmax features are smooth: outputs and every gradient must agree to 1e-5 / 2e-5.
@@ -442,7 +443,11 @@ def test_layer_vs_oracle_ba_graphs(generalized, fused):
     rounding of 0 (|pre| ~ 1e-8), where the CPU GEMM and the GPU GEMM feeding the map legitimately disagree on
     the sign and hence on relu'(pre) in {0, 1}.  Such a flip changes the gradient of ONE row by O(1e-3) and is
     not a parity defect (the fp64 oracle sides with either).  So for ReLU: outputs strict, gradients strict on
-    all but <= 0.2 % of the rows, parameter gradients to 1e-3.  The small golden cases pin ReLU gradients at 2e-5."""
+    all but <= 0.2 % of the rows, parameter gradients to 1e-3.  The small golden cases pin ReLU gradients at 2e-5.
+
+    dqk = 64: the head shape of the reference's other shipped configuration (regression/examples/pcqm4m-lsc/enc.sh:3:
+    dim_qk = dim_v = 64, 4 heads -> head width 16, m = int(16 ln 16) = 44 features, value width 16), which runs the general
+    kernels (csrc/attn.hip, csrc/phi.hip) at sizes the 8 x 16 specialisations do not cover."""
     _, _, _, bs, KernelFeatureMap, ms, _ = _product()
     from oracle import hot_oracle as O
     nfs, eis, efs, g = _ba_case(12, 5)
@@ -451,7 +456,9 @@ def test_layer_vs_oracle_ba_graphs(generalized, fused):
     assert np.array_equal(G0.t_indices.cpu().numpy(), GO.t_indices.numpy())
     assert np.array_equal(G0.t_mask.cpu().numpy(), GO.t_mask.numpy())
     torch.manual_seed(0)
-    layer = ms.KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8, generalized_attention=generalized)).to(DEV)
+    layer = ms.KernelSelfAttn(2, 2, 32, dqk, dqk, 4, 'default', 0., 0.,
+                              KernelFeatureMap(dqk // 4, generalized_attention=generalized)).to(DEV)
+    assert layer.feat_dim == (16 if dqk == 32 else 44)
     layer.use_fused = fused
     sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
           for k, v in layer.state_dict().items()}
@@ -460,7 +467,7 @@ def test_layer_vs_oracle_ba_graphs(generalized, fused):
     R = torch.randn(y.values.shape, generator=g)
     (y.values * R.to(DEV)).sum().backward()
     xo = GO.values.clone().requires_grad_(True)
-    yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, 32, 32, 4, 'default', generalized)
+    yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, dqk, dqk, 4, 'default', generalized)
     (yo.values * R).sum().backward()
     e_y = rel_err(y.values.detach().cpu(), yo.values.detach())
     assert e_y < TOL, e_y
