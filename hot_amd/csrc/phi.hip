@@ -110,6 +110,96 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_bwd(const float* __res
   }
 }
 
+// Head widths d in {4, 8, 16, 32} with 16-byte aligned rows (the other shipped shape, enc.sh: d = 16, m = 44).  A block walks
+// whole rows (no 64-bit division per element); the projection sits in LDS with rows padded to d + 1 floats so that 64
+// consecutive features read 64 distinct banks; the head slice of x arrives as d / 4 16-byte loads shared by the lanes of
+// the head.  Same fmaf chains as proj_dot: identical bits (and identical gates in the backward).
+template <int D>
+__device__ __forceinline__ float proj_dot_v(const float* __restrict__ xs, const float* __restrict__ pr, float scale) {
+  float s = 0.f;
+#pragma unroll
+  for (int q = 0; q < D / 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(xs + 4 * q);
+    s = fmaf(v.x * scale, pr[4 * q + 0], s);
+    s = fmaf(v.y * scale, pr[4 * q + 1], s);
+    s = fmaf(v.z * scale, pr[4 * q + 2], s);
+    s = fmaf(v.w * scale, pr[4 * q + 3], s);
+  }
+  return s;
+}
+template <int D>
+__device__ __forceinline__ void stage_proj_padded(float* lds, const float* __restrict__ proj, int m) {
+  for (int i = threadIdx.x; i < m * D; i += blockDim.x) lds[(i / D) * (D + 1) + (i % D)] = proj[i];
+  __syncthreads();
+}
+constexpr int PHI_MAX_M = 128;                 // features per head these kernels hold in LDS (padded rows of D + 1 floats)
+
+template <int D>
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd_d(const float* __restrict__ x, int64_t ld_x,
+                                                                const float* __restrict__ proj,
+                                                                const uint8_t* __restrict__ kind, unsigned keep,
+                                                                float* __restrict__ phi, int64_t ld_phi, int64_t n,
+                                                                int HH, int m, float scale, float eps) {
+  __shared__ float P[PHI_MAX_M * (D + 1)];
+  stage_proj_padded<D>(P, proj, m);
+  const int F = HH * m;
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const bool on = !kind || hotk_keep(keep, kind[r]);
+    const float* xr = x + r * ld_x;
+    float* pr = phi + r * ld_phi;
+    for (int f = threadIdx.x; f < F; f += PHI_THREADS) {
+      const int hh = f / m, mm = f - hh * m;
+      float o = 0.f;
+      if (on) o = fmaxf(proj_dot_v<D>(xr + hh * D, P + mm * (D + 1), scale), 0.f) + eps;
+      pr[f] = o;
+    }
+  }
+}
+
+// backward: thread (head-slot hh, k) of a row; the D threads of a head-slot are consecutive lanes.  Phase A: thread k
+// recomputes the pre-activations of features k, k + D, ... (the forward's chain: identical gate) and leaves the gated
+// gradients in LDS; phase B: it contracts them with column k of the projection in feature order, as the one-thread-per-
+// element kernel does (same bits), at (m + D ceil(m / D)) instead of m (D + 1) multiply-adds per output element.
+template <int D>
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_bwd_d(const float* __restrict__ x, int64_t ld_x,
+                                                                const float* __restrict__ proj,
+                                                                const uint8_t* __restrict__ kind, unsigned keep,
+                                                                const float* __restrict__ dphi, int64_t ld_dphi,
+                                                                float* __restrict__ dx, int64_t ld_dx, int64_t n, int HH,
+                                                                int m, float scale) {
+  __shared__ float P[PHI_MAX_M * (D + 1)];
+  __shared__ float gs[(PHI_THREADS / D) * PHI_MAX_M];
+  stage_proj_padded<D>(P, proj, m);
+  const int C = HH * D;
+  const int k = threadIdx.x % D, slot = threadIdx.x / D;
+  float* g = gs + slot * m;
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const bool on = !kind || hotk_keep(keep, kind[r]);
+    const float* xr = x + r * ld_x;
+    const float* gr = dphi + r * ld_dphi;
+    for (int c0 = 0; c0 < C; c0 += PHI_THREADS) {   // block-uniform trip count: the barriers below are reached by all
+      const int c = c0 + threadIdx.x, hh = c / D;
+      const bool act = on && c < C;
+      if (act) {
+        for (int mm = k; mm < m; mm += D) {
+          const float pre = proj_dot_v<D>(xr + hh * D, P + mm * (D + 1), scale);
+          g[mm] = pre > 0.f ? gr[hh * m + mm] : 0.f;
+        }
+      }
+      __syncthreads();
+      if (c < C) {
+        float acc = 0.f;
+        if (on) {
+          for (int mm = 0; mm < m; ++mm) acc = fmaf(g[mm], P[mm * (D + 1) + k], acc);
+          acc *= scale;
+        }
+        dx[r * ld_dx + c] = acc;
+      }
+      __syncthreads();
+    }
+  }
+}
+
 // d == 8, m == 16: the backward twin of k_phi_relu_fwd_8x16.  Thread (head, feature mm) recomputes ITS pre-activation
 // (the forward's fmaf chain: identical gate), the 16 gated gradients of a head meet in LDS, and the head's threads
 // mm < 8 contract them with column k = mm of the projection (held in registers), in feature order like the generic
@@ -363,6 +453,11 @@ __global__ __launch_bounds__(PHI_THREADS) void k_reduce_sum2_final(const float* 
 
 constexpr int STATS_BLOCKS = 1024;
 
+// the row-walking ReLU kernels: head width 4 / 8 / 16 / 32, 16-byte aligned head slices, padded projection fits LDS
+bool phi_vec_ok(const float* x, int64_t ld_x, int d, int m) {
+  return (d == 4 || d == 8 || d == 16 || d == 32) && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0 && m <= PHI_MAX_M;
+}
+
 int phi_check(int64_t n, int HH, int d, int m, int mode) {
   if (n < 0 || HH <= 0 || d <= 0 || m <= 0) return HOTK_EINVAL;
   if (mode < 0 || mode > 2) return HOTK_EINVAL;
@@ -385,6 +480,14 @@ extern "C" int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, con
   if (mode == HOTK_PHI_RELU && d == 8 && m == 16 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0) {
     hipLaunchKernelGGL(k_phi_relu_fwd_8x16, dim3(hotk_grid(n, 1, 256 * 32)), dim3(PHI_THREADS), 0, st, x,
                        ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
+  } else if (mode == HOTK_PHI_RELU && phi_vec_ok(x, ld_x, d, m)) {
+    const dim3 grid(hotk_grid(n, 1, 256 * 32)), block(PHI_THREADS);
+    switch (d) {
+      case 4: hipLaunchKernelGGL(k_phi_relu_fwd_d<4>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-3f); break;
+      case 8: hipLaunchKernelGGL(k_phi_relu_fwd_d<8>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-3f); break;
+      case 16: hipLaunchKernelGGL(k_phi_relu_fwd_d<16>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-3f); break;
+      default: hipLaunchKernelGGL(k_phi_relu_fwd_d<32>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-3f);
+    }
   } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_fwd, dim3(hotk_grid(n * HH * m, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, phi, ld_phi, n, HH, d, m, scale, 1e-3f);
@@ -409,6 +512,14 @@ extern "C" int hotk_phi_bwd(const float* x, int64_t ld_x, const float* proj, con
   if (mode == HOTK_PHI_RELU && d == 8 && m == 16 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0) {
     hipLaunchKernelGGL(k_phi_relu_bwd_8x16, dim3(hotk_grid(n, 1, 256 * 32)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, scale);
+  } else if (mode == HOTK_PHI_RELU && phi_vec_ok(x, ld_x, d, m)) {
+    const dim3 grid(hotk_grid(n, 1, 256 * 32)), block(PHI_THREADS);
+    switch (d) {
+      case 4: hipLaunchKernelGGL(k_phi_relu_bwd_d<4>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale); break;
+      case 8: hipLaunchKernelGGL(k_phi_relu_bwd_d<8>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale); break;
+      case 16: hipLaunchKernelGGL(k_phi_relu_bwd_d<16>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale); break;
+      default: hipLaunchKernelGGL(k_phi_relu_bwd_d<32>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale);
+    }
   } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_bwd, dim3(hotk_grid(n * HH * d, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, d, m, scale);
