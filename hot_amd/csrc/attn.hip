@@ -247,6 +247,166 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
   }
 }
 
+// The same map with a wave per (row, 64 consecutive features) for c in {8, 16} and 16-byte aligned X rows: the wave's
+// key-value rows KV[s][f0 .. f0 + 64)[0 .. c] are ONE contiguous block of 64 (c + 1) floats, fetched with c + 1 coalesced
+// loads into a wave-private LDS image and read back one row per lane (stride c + 1, odd: no bank conflicts) -- the
+// thread-per-element kernel reads them as c + 1 loads whose lanes are 4 (c + 1) bytes apart (~34 cache lines per
+// instruction at c = 16).  Same fmaf order per element: identical bits.
+constexpr int RX_WAVES = 4;
+constexpr int RX_ROWS = 8;   // consecutive rows a wave walks per feature group: rows that share a segment (sorted entry
+                             // lists, graph-keyed sums) reuse the key-value rows already in registers
+template <int C>
+__global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
+    const float* __restrict__ KV, const int32_t* __restrict__ sidx, int64_t seg_div, const float* __restrict__ X,
+    int64_t ld_x, const int32_t* __restrict__ xidx, const float* __restrict__ XA, int64_t ld_xa,
+    const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out, int64_t ld_out, int64_t n, int HH, int m) {
+  constexpr int c1 = C + 1;
+  __shared__ float img_all[RX_WAVES][64 * c1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* img = img_all[wave];
+  const int F = HH * m, NG = (F + 63) >> 6;
+  const int64_t chunks = (n + RX_ROWS - 1) / RX_ROWS;
+  const int64_t items = chunks * NG;
+  const bool small = items < (int64_t)0x7fffffff;
+  for (int64_t w = (int64_t)blockIdx.x * RX_WAVES + wave; w < items; w += (int64_t)gridDim.x * RX_WAVES) {
+    const int64_t ch = small ? (int64_t)((uint32_t)w / (uint32_t)NG) : w / NG;
+    const int f0 = (int)(w - ch * NG) << 6;
+    const int nf = F - f0 < 64 ? F - f0 : 64;
+    const int len = nf * c1;
+    const int f = f0 + lane;
+    const int hh = (lane < nf ? f : f0) / m;
+    const int64_t r0 = ch * RX_ROWS, r1 = r0 + RX_ROWS < n ? r0 + RX_ROWS : n;
+    // the segment of row r, or -1 when the row's output is zero (wave-uniform)
+    auto seg_on = [&](int64_t r) -> int64_t {
+      const int64_t sg = seg_of(sidx, seg_div, r);
+      return (sg >= 0 && (!kind || hotk_keep(keep, kind[r]))) ? sg : -1;
+    };
+    float kv[c1], pre[c1];
+#pragma unroll
+    for (int k = 0; k < c1; ++k) kv[k] = pre[k] = 0.f;
+    int64_t s_cur = -1, s_nxt = seg_on(r0);
+    auto fetch = [&](int64_t sg) {          // the block's 64 (c + 1) floats, coalesced, into registers
+      const float* blk = KV + (sg * F + f0) * c1;
+#pragma unroll
+      for (int k = 0; k < c1; ++k) {
+        const int i = lane + 64 * k;
+        if (i < len) pre[k] = blk[i];
+      }
+    };
+    if (s_nxt >= 0) fetch(s_nxt);
+    for (int64_t r = r0; r < r1; ++r) {
+      const int64_t sg = s_nxt;
+      if (sg >= 0 && sg != s_cur) {         // transpose through the wave's LDS image: lane <- row lane of the block
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < c1; ++k) {
+          const int i = lane + 64 * k;
+          if (i < len) img[i] = pre[k];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nf) {
+#pragma unroll
+          for (int k = 0; k < c1; ++k) kv[k] = img[lane * c1 + k];
+        }
+        s_cur = sg;
+      }
+      // this row's operands first, then the next row's key-value block: the block's latency hides behind this row
+      float4 xv[C / 4];
+      float xa = 1.f;
+      const int64_t xr = xidx ? (int64_t)xidx[r] : r;
+      if (sg >= 0 && lane < nf) {
+        if (xr >= 0) {
+          const float* xp = X + xr * ld_x + hh * C;
+#pragma unroll
+          for (int q = 0; q < C / 4; ++q) xv[q] = *reinterpret_cast<const float4*>(xp + 4 * q);
+        }
+        if (XA) xa = XA[r * ld_xa + hh];
+      }
+      if (r + 1 < r1) {
+        s_nxt = seg_on(r + 1);
+        if (s_nxt >= 0 && s_nxt != s_cur) fetch(s_nxt);
+      }
+      float o = 0.f;
+      if (sg >= 0 && lane < nf) {
+        if (xr >= 0) {
+#pragma unroll
+          for (int q = 0; q < C / 4; ++q) {
+            o = fmaf(kv[4 * q + 0], xv[q].x, o); o = fmaf(kv[4 * q + 1], xv[q].y, o);
+            o = fmaf(kv[4 * q + 2], xv[q].z, o); o = fmaf(kv[4 * q + 3], xv[q].w, o);
+          }
+        }
+        o = fmaf(kv[C], xa, o);
+      }
+      if (lane < nf) out[r * ld_out + f] = o;
+    }
+  }
+}
+
+// Key-value sums with a thread per (segment, feature) holding all c + 1 accumulators (c in {8, 16}: ONE walk of the
+// segment, the head's values as 16-byte loads) and the wave's 64 result rows -- one contiguous block of 64 (c + 1) floats
+// -- leaving through an LDS image as c + 1 coalesced stores instead of c + 1 stores with lanes 4 (c + 1) bytes apart.
+// Same fmaf order per accumulator as k_seg_outer_sum: identical bits.
+template <int C>
+__global__ __launch_bounds__(64 * RX_WAVES) void k_seg_outer_sum_w(
+    const float* __restrict__ K, int64_t ld_k, const int32_t* __restrict__ kidx, const float* __restrict__ V,
+    int64_t ld_v, const int32_t* __restrict__ vidx, const float* __restrict__ aug, int64_t ld_aug,
+    const int32_t* __restrict__ seg_begin, const int32_t* __restrict__ seg_end, const int32_t* __restrict__ perm,
+    float* __restrict__ KV, int64_t n_seg, int HH, int m) {
+  constexpr int c1 = C + 1;
+  __shared__ float img_all[RX_WAVES][64 * c1];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* img = img_all[wave];
+  const int F = HH * m, NG = (F + 63) >> 6;
+  const int64_t items = n_seg * NG;
+  for (int64_t w = (int64_t)blockIdx.x * RX_WAVES + wave; w < items; w += (int64_t)gridDim.x * RX_WAVES) {
+    const int64_t s = w / NG;
+    const int f0 = (int)(w - s * NG) << 6;
+    const int nf = F - f0 < 64 ? F - f0 : 64;
+    const int f = f0 + (lane < nf ? lane : nf - 1);     // idle lanes shadow the last feature (no divergent loop bounds)
+    const int hh = f / m;
+    const int64_t lo = seg_begin[s], hi = seg_end[s];
+    float acc[c1];
+#pragma unroll
+    for (int k = 0; k < c1; ++k) acc[k] = 0.f;
+    for (int64_t p = lo; p < hi; ++p) {
+      const int64_t r = perm ? (int64_t)perm[p] : p;
+      const int64_t kr = kidx ? (int64_t)kidx[r] : r;
+      if (kr < 0) continue;
+      const float kv = K[kr * ld_k + f];
+      const int64_t vr = vidx ? (int64_t)vidx[r] : r;
+      const float va = aug ? aug[r * ld_aug + hh] : 1.f;
+      if (vr >= 0) {
+        const float* vp = V + vr * ld_v + hh * C;
+#pragma unroll
+        for (int q = 0; q < C / 4; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(vp + 4 * q);
+          acc[4 * q + 0] = fmaf(kv, v.x, acc[4 * q + 0]); acc[4 * q + 1] = fmaf(kv, v.y, acc[4 * q + 1]);
+          acc[4 * q + 2] = fmaf(kv, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(kv, v.w, acc[4 * q + 3]);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < C; ++k) acc[k] = fmaf(kv, 0.f, acc[k]);
+      }
+      acc[C] = fmaf(kv, va, acc[C]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < c1; ++k) img[lane * c1 + k] = acc[k];
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* blk = KV + ((int64_t)s * F + f0) * c1;
+    const int len = nf * c1;
+#pragma unroll
+    for (int k = 0; k < c1; ++k) {
+      const int i = lane + 64 * k;
+      if (i < len) blk[i] = img[i];
+    }
+  }
+}
+
 int dims_ok(int HH, int m, int c) { return HH > 0 && m > 0 && c > 0; }
 
 }  // namespace
@@ -267,7 +427,16 @@ extern "C" int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* k
   int Fp = (HH * m + 63) & ~63;
   int64_t work = n_seg * n_chunk * n_tile * Fp;
   static_assert(AT_CT == 9, "the C8 form keeps 8 values + the normaliser in one tile");
-  const bool c8 = c == 8 && (ld_v & 3) == 0 && hotk_aligned16(V);
+  const bool v16 = (ld_v & 3) == 0 && hotk_aligned16(V);
+  // c = 16 (and c = 8 when a feature group is not a whole number of heads' worth of one-tile work): the wave form
+  if (c == 16 && v16) {
+    const int64_t items = n_seg * ((HH * m + 63) / 64);
+    hipLaunchKernelGGL(k_seg_outer_sum_w<16>, dim3(hotk_grid(items, RX_WAVES, 256 * 32)), dim3(64 * RX_WAVES), 0,
+                       (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug, ld_aug, seg_begin, seg_end, perm, KV, n_seg,
+                       HH, m);
+    return hotk_launch_status();
+  }
+  const bool c8 = c == 8 && v16;
   if (c8)
     hipLaunchKernelGGL(k_seg_outer_sum<true>, dim3(hotk_grid(work, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
                        (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug, ld_aug, seg_begin, seg_end, perm, KV,
@@ -323,6 +492,12 @@ extern "C" int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(KV && X && out && ld_x >= (int64_t)HH * c && ld_out >= (int64_t)HH * m && (!XA || ld_xa >= HH));
+  if (c == 16 && (ld_x & 3) == 0 && hotk_aligned16(X)) {
+    const int64_t items = ((n + RX_ROWS - 1) / RX_ROWS) * ((HH * m + 63) / 64);
+    hipLaunchKernelGGL(k_row_expand_w<16>, dim3(hotk_grid(items, RX_WAVES, 256 * 32)), dim3(64 * RX_WAVES), 0,
+                       (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA, ld_xa, kind, keep, out, ld_out, n, HH, m);
+    return hotk_launch_status();
+  }
   hipLaunchKernelGGL(k_row_expand, dim3(hotk_grid(n * HH * m, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
                      (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA, ld_xa, kind, keep, out, ld_out, n, HH,
                      m, c);
