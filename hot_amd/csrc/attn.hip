@@ -179,6 +179,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
   const int64_t total = n * W;
   // every lane of a wave runs the same number of iterations (total is padded), so the shuffles see whole groups
   const int64_t padded = (total + 63) & ~(int64_t)63;
+  const bool q4 = (m & 3) == 0 && (ld_q & 3) == 0 && (((uintptr_t)Q) & 15u) == 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += (int64_t)gridDim.x * blockDim.x) {
     const bool live = t < total;
     const int64_t r = live ? t / W : 0;
@@ -192,10 +193,21 @@ __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
       const float* q = Q + r * ld_q + hh * m;
       const float* kv = KV + ((int64_t)s * F + hh * m) * c1;
       float num = 0.f, den = 0.f;
-      for (int mm = 0; mm < m; ++mm) {
-        const float qv = q[mm];
-        num = fmaf(qv, kv[mm * c1 + chn], num);
-        den = fmaf(qv, kv[mm * c1 + C], den);
+      if (q4) {   // m % 4 == 0, 16-byte aligned rows: the query slice as vector loads (same fmaf order)
+        for (int mm = 0; mm < m; mm += 4) {
+          const float4 qv = *reinterpret_cast<const float4*>(q + mm);
+          const float* k0 = kv + mm * c1;
+          num = fmaf(qv.x, k0[chn], num);          den = fmaf(qv.x, k0[C], den);
+          num = fmaf(qv.y, k0[c1 + chn], num);     den = fmaf(qv.y, k0[c1 + C], den);
+          num = fmaf(qv.z, k0[2 * c1 + chn], num); den = fmaf(qv.z, k0[2 * c1 + C], den);
+          num = fmaf(qv.w, k0[3 * c1 + chn], num); den = fmaf(qv.w, k0[3 * c1 + C], den);
+        }
+      } else {
+        for (int mm = 0; mm < m; ++mm) {
+          const float qv = q[mm];
+          num = fmaf(qv, kv[mm * c1 + chn], num);
+          den = fmaf(qv, kv[mm * c1 + C], den);
+        }
       }
       guarded = (den == 0.f);
       if (guarded) den = 1e-5f;
@@ -252,6 +264,9 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
 // loads into a wave-private LDS image and read back one row per lane (stride c + 1, odd: no bank conflicts) -- the
 // thread-per-element kernel reads them as c + 1 loads whose lanes are 4 (c + 1) bytes apart (~34 cache lines per
 // instruction at c = 16).  Same fmaf order per element: identical bits.
+#ifndef HOTK_WAVE_C8
+#define HOTK_WAVE_C8 1
+#endif
 constexpr int RX_WAVES = 4;
 constexpr int RX_ROWS = 8;   // consecutive rows a wave walks per feature group: rows that share a segment (sorted entry
                              // lists, graph-keyed sums) reuse the key-value rows already in registers
@@ -428,12 +443,16 @@ extern "C" int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* k
   int64_t work = n_seg * n_chunk * n_tile * Fp;
   static_assert(AT_CT == 9, "the C8 form keeps 8 values + the normaliser in one tile");
   const bool v16 = (ld_v & 3) == 0 && hotk_aligned16(V);
-  // c = 16 (and c = 8 when a feature group is not a whole number of heads' worth of one-tile work): the wave form
-  if (c == 16 && v16) {
+  // c in {8, 16} with 16-byte aligned value rows: the wave form
+  if ((c == 16 || (c == 8 && HOTK_WAVE_C8)) && v16) {
     const int64_t items = n_seg * ((HH * m + 63) / 64);
-    hipLaunchKernelGGL(k_seg_outer_sum_w<16>, dim3(hotk_grid(items, RX_WAVES, 256 * 32)), dim3(64 * RX_WAVES), 0,
-                       (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug, ld_aug, seg_begin, seg_end, perm, KV, n_seg,
-                       HH, m);
+    const dim3 grid(hotk_grid(items, RX_WAVES, 256 * 32)), block(64 * RX_WAVES);
+    if (c == 16)
+      hipLaunchKernelGGL(k_seg_outer_sum_w<16>, grid, block, 0, (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug,
+                         ld_aug, seg_begin, seg_end, perm, KV, n_seg, HH, m);
+    else
+      hipLaunchKernelGGL(k_seg_outer_sum_w<8>, grid, block, 0, (hipStream_t)stream, K, ld_k, kidx, V, ld_v, vidx, aug,
+                         ld_aug, seg_begin, seg_end, perm, KV, n_seg, HH, m);
     return hotk_launch_status();
   }
   const bool c8 = c == 8 && v16;
@@ -492,10 +511,15 @@ extern "C" int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(KV && X && out && ld_x >= (int64_t)HH * c && ld_out >= (int64_t)HH * m && (!XA || ld_xa >= HH));
-  if (c == 16 && (ld_x & 3) == 0 && hotk_aligned16(X)) {
+  if ((c == 16 || (c == 8 && HOTK_WAVE_C8)) && (ld_x & 3) == 0 && hotk_aligned16(X)) {
     const int64_t items = ((n + RX_ROWS - 1) / RX_ROWS) * ((HH * m + 63) / 64);
-    hipLaunchKernelGGL(k_row_expand_w<16>, dim3(hotk_grid(items, RX_WAVES, 256 * 32)), dim3(64 * RX_WAVES), 0,
-                       (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA, ld_xa, kind, keep, out, ld_out, n, HH, m);
+    const dim3 grid(hotk_grid(items, RX_WAVES, 256 * 32)), block(64 * RX_WAVES);
+    if (c == 16)
+      hipLaunchKernelGGL(k_row_expand_w<16>, grid, block, 0, (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA,
+                         ld_xa, kind, keep, out, ld_out, n, HH, m);
+    else
+      hipLaunchKernelGGL(k_row_expand_w<8>, grid, block, 0, (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA,
+                         ld_xa, kind, keep, out, ld_out, n, HH, m);
     return hotk_launch_status();
   }
   hipLaunchKernelGGL(k_row_expand, dim3(hotk_grid(n * HH * m, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
