@@ -764,3 +764,102 @@ def test_bf16_storage_mode_ragged_and_dropout():
         assert rel_err(y1.cpu(), y0.cpu()) < 2e-2 and rel_err(g1.cpu(), g0.cpu()) < 2e-2, train
         assert max(e_p.values()) < 2e-2, (train, e_p)
         assert float(y1[~G0.mask].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize('HH,m,c', [(4, 16, 8), (4, 44, 16), (2, 10, 16), (8, 16, 8), (3, 5, 4)])
+def test_general_attention_kernels_masks_and_indices(HH, m, c):
+    """The four general attention entry points (csrc/attn.hip; kernelattncoef.py:19-71,103-175) called on their own with
+    everything the layers can hand them -- index maps with -1 rows, segment ids with -1, row-kind masks, ragged feature
+    counts, row counts that fill no whole tile -- against fp64 numpy on the same inputs; and, for the shapes that take
+    the wave kernels (c in {8, 16}, 16-byte aligned rows), bit for bit against the thread-per-element kernels, which
+    the same call takes when its operand rows are not 16-byte aligned (same fmaf order per element)."""
+    from hot_amd import ops, _lib
+    g = torch.Generator().manual_seed(100 * HH + m + c)
+    n, n_seg, n_src = 1237, 97, 411
+    F, Wd = HH * m, HH * c
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    K, V, aug = rnd(n_src, F).abs(), rnd(n_src, Wd), rnd(n, HH).abs() + 0.5
+    Q, dO, Xsrc, XAsrc = rnd(n, F).abs(), rnd(n, Wd), rnd(n_src, Wd), rnd(n, HH)
+    kidx = torch.randint(-1, n_src, (n,), generator=g).to(torch.int32)
+    vidx = torch.randint(-1, n_src, (n,), generator=g).to(torch.int32)
+    # segments: a permutation of the rows cut into n_seg ragged pieces (some empty)
+    perm = torch.randperm(n, generator=g).to(torch.int32)
+    cuts = torch.sort(torch.randint(0, n + 1, (n_seg - 1,), generator=g)).values
+    beg = torch.cat([torch.zeros(1, dtype=torch.long), cuts]).to(torch.int32)
+    end = torch.cat([cuts, torch.tensor([n])]).to(torch.int32)
+    maxlen = int((end - beg).max())
+
+    def padded(t, pad):      # the same values in rows that are (pad = 1: not) 16-byte aligned
+        w = torch.zeros(t.size(0), t.size(1) + 4 + pad, device=DEV)
+        w[:, pad:pad + t.size(1)] = t.to(DEV)
+        return w[:, pad:pad + t.size(1)]
+
+    dev = lambda t: t.to(DEV)
+    seg = (dev(beg), dev(end), dev(perm), maxlen)
+    outs = {}
+    for pad in (0, 1):
+        Kd, Vd, augd = padded(K, pad), padded(V, pad), padded(aug, pad)
+        KV = ops.seg_outer_sum(Kd, dev(kidx), Vd, dev(vidx), augd, seg, HH, m, c)
+        # queries / gradients per row, segments per row with -1, kinds
+        g2 = torch.Generator().manual_seed(7)
+        sidx = torch.randint(-1, n_seg, (n,), generator=g2).to(torch.int32)
+        sidx[100:140] = 5                       # a run of rows on one segment
+        kind = torch.randint(0, 3, (n,), generator=g2).to(torch.uint8)
+        qidx = torch.randint(-1, n, (n,), generator=g2).to(torch.int32)
+        Qd, dOd = padded(Q, pad), padded(dO, pad)
+        O = ops.row_contract(Qd, dev(qidx), KV, dev(sidx), 1, dev(kind), _lib.KEEP_OFFDIAG, n, HH, m, c, True)
+        On = ops.row_contract(Qd, None, KV, dev(sidx), 1, None, 0, n, HH, m, c, False)
+        X, XA = ops.apply_bwd_stats(Qd, KV, dev(sidx), 1, dev(kind), _lib.KEEP_VALID, dOd, n, HH, m, c)
+        Xin, XAin = padded(Xsrc, pad), padded(XAsrc, pad)
+        E = ops.row_expand(KV, dev(sidx), 1, Xin, dev(vidx), XAin, dev(kind), _lib.KEEP_VALID, n, HH, m, c)
+        E1 = ops.row_expand(KV, None, 13, Xin, None, None, None, 0, n_src, HH, m, c)     # segment = row // 13, no masks
+        outs[pad] = [t.cpu() for t in (KV, O, On, X, XA, E, E1)]
+        if pad == 0:
+            ins = dict(Q=Q, dO=dO, sidx=sidx, kind=kind, qidx=qidx, Xin=Xsrc, XAin=XAsrc)
+    KV, O, On, X, XA, E, E1 = outs[0]
+    if c in (8, 16):      # wave kernels vs thread-per-element kernels
+        for a, b in zip(outs[0], outs[1]):
+            assert torch.equal(a, b)
+    # fp64 references
+    Kn, Vn, an = K.double().numpy(), V.double().numpy(), aug.double().numpy()
+    ref = np.zeros((n_seg, HH, m, c + 1))
+    pm = perm.numpy()
+    for s_ in range(n_seg):
+        for r in pm[int(beg[s_]):int(end[s_])]:
+            if kidx[r] < 0:
+                continue
+            kk = Kn[kidx[r]].reshape(HH, m)
+            vv = Vn[vidx[r]].reshape(HH, c) if vidx[r] >= 0 else np.zeros((HH, c))
+            ref[s_, :, :, :c] += kk[:, :, None] * vv[:, None, :]
+            ref[s_, :, :, c] += kk * an[r][:, None]
+    assert rel_err(KV, torch.from_numpy(ref.reshape(n_seg, F, c + 1)).float()) < TOL
+    KVn = KV.double().numpy().reshape(n_seg, HH, m, c + 1)
+    Qn, dOn = ins['Q'].double().numpy().reshape(n, HH, m), ins['dO'].double().numpy().reshape(n, HH, c)
+    sidx, kind, qidx = ins['sidx'].numpy(), ins['kind'].numpy(), ins['qidx'].numpy()
+    rO, rOn, rX, rXA = np.zeros((n, HH, c)), np.zeros((n, HH, c)), np.zeros((n, HH, c)), np.zeros((n, HH))
+    rE = np.zeros((n, HH, m))
+    Xn, XAn = ins['Xin'].double().numpy().reshape(-1, HH, c), ins['XAin'].double().numpy()
+    for r in range(n):
+        s_ = sidx[r]
+        if s_ < 0:
+            continue
+        kv = KVn[s_]
+        numq = np.einsum('hm,hmc->hc', Qn[r], kv)
+        rOn[r] = numq[:, :c]
+        if kind[r] == 2 and qidx[r] >= 0:
+            nq = np.einsum('hm,hmc->hc', Qn[qidx[r]], kv)
+            den = np.where(nq[:, c] == 0, 1e-5, nq[:, c])
+            rO[r] = nq[:, :c] / den[:, None]
+        if kind[r] != 0:
+            den = np.where(numq[:, c] == 0, 1e-5, numq[:, c])
+            rX[r] = dOn[r] / den[:, None]
+            rXA[r] = -(dOn[r] * numq[:, :c]).sum(-1) / den ** 2
+            xx = Xn[vidx[r]] if vidx[r] >= 0 else np.zeros((HH, c))
+            rE[r] = np.einsum('hmc,hc->hm', kv[:, :, :c], xx) + kv[:, :, c] * XAn[r][:, None]
+    f32 = lambda a, *s: torch.from_numpy(a.reshape(*s)).float()
+    assert rel_err(On, f32(rOn, n, Wd)) < TOL and rel_err(O, f32(rO, n, Wd)) < TOL
+    assert rel_err(X, f32(rX, n, Wd)) < TOL and rel_err(XA, f32(rXA, n, HH)) < 2 * TOL
+    assert rel_err(E, f32(rE, n, F)) < TOL
+    n1 = n_src
+    rE1 = np.einsum('rhmc,rhc->rhm', KVn[np.arange(n1) // 13][:, :, :, :c], Xn[:n1]) + KVn[np.arange(n1) // 13][:, :, :, c]
+    assert rel_err(E1, f32(rE1, n1, F)) < TOL
