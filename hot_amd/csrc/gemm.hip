@@ -20,6 +20,7 @@
 // loop), so their latency overlaps the matrix work.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -49,6 +50,9 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, uint32_t& hi, ui
 __device__ __forceinline__ f32x16 mfma_bf16(const u32x4& a, const u32x4& b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
+#ifndef HOTK_WIDE_WAVES
+#define HOTK_WIDE_WAVES 8
+#endif
 #ifndef HOTK_ENTRY_WAVES
 #define HOTK_ENTRY_WAVES 8   /* measured at 10 M rows: 4 waves 7.9 ms, 8 waves 6.1 ms, 16 waves (128 VGPRs, spills) 6.7 ms */
 #endif
@@ -108,7 +112,11 @@ __device__ __forceinline__ void gemm_wave_fence() {
 
 // B6: the products run as six bf16 MFMAs per 16 k (see above).  The weight sits in LDS as three bf16 planes
 // [plane][k / 16][col][16 k] (a lane's A fragment = one ds_read_b128), the lane's 32 row values are split once per tile.
-template <int KH, int TG, int MODE, int NW, bool B6 = false>
+// RES: MODE 0 with a residual; OB: bf16 result.  Compile-time, like FULL below (a row tile with all 32 rows inside the
+// matrix): the epilogue then has no branch around its stores, the compiler can COUNT them, and the wait for the
+// prefetched addends of the next tile becomes vmcnt(4) instead of vmcnt(0) -- a wait for every store of the tile to
+// complete (loads and stores share the in-order counter).
+template <int KH, int TG, int MODE, int NW, bool B6 = false, bool RES = false, bool OB = false>
 __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                           float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
   constexpr int WAVES = NW;
@@ -136,16 +144,26 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
   } else {
     for (int i = tid * 4; i < K * C; i += 64 * WAVES * 4) *reinterpret_cast<float4*>(w_lds + i) = *reinterpret_cast<const float4*>(W + i);
   }
+  // both bias vectors behind the result images (zeros when absent): an epilogue that fetched them from global memory
+  // between its stores waited for every store to complete first -- loads and stores share one in-order counter
+  float* b_lds = w_lds + w_floats + WAVES * 32 * OS;     // [2][C]: MODE 0: bias | unused; MODE 1: b_diag | b_off
+  for (int i = tid; i < C; i += 64 * WAVES) {
+    const float* b0 = MODE == 1 ? ep.b_diag : ep.bias;
+    b_lds[i] = b0 ? b0[i] : 0.f;
+    if (MODE == 1) b_lds[C + i] = ep.b_off ? ep.b_off[i] : 0.f;
+  }
   __syncthreads();
   const int wave = tid >> 6, lane = tid & 63, j = lane & 31, half = lane >> 5;
   float* img = w_lds + w_floats + wave * 32 * OS;
   const int er = lane >> 3, ec = 4 * (lane & 7);       // epilogue: rows 8 i + er, columns ec .. ec + 3 of a tile
-  const bool has_res = MODE == 0 && ep.res != nullptr;
+  constexpr bool has_res = MODE == 0 && RES;
   const int64_t n_tiles = (R + 32 * WAVES - 1) / (32 * WAVES);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * (32 * WAVES) + wave * 32;
     if (row0 >= R) continue;
-    const int64_t row = row0 + j < R ? row0 + j : R - 1;      // rows past the end re-read the last row and store nothing
+    auto row_tile = [&](auto full_tag) __attribute__((always_inline)) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int64_t row = (FULL || row0 + j < R) ? row0 + j : R - 1;      // rows past the end re-read the last row and store nothing
     // per-row epilogue operands: MODE 1 folds the three row kinds into two gathered rows, two multipliers and a bias
     // selector (x2 is zero on diagonal and padding rows, so the accumulator contributes nothing there):
     //   off-diagonal: acc + yn[i][C..) + yn[j][2C..) + b_off    diagonal: 0 + yn[v][0..) + 0 + b_diag    padding: 0
@@ -153,7 +171,7 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t rr = row0 + 8 * i + er;
-      const bool live = rr < R;
+      const bool live = FULL || rr < R;
       const int64_t rc = live ? rr : R - 1;
       rm[i].o1 = rm[i].o2 = 0;
       rm[i].kd = live ? 1 : 0;
@@ -171,7 +189,6 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
         rm[i].pres = ep.res + rc * ep.ld_res + ec;
       }
     }
-    const float* pb_any = (MODE == 1 ? (ep.b_off ? ep.b_off : (ep.b_diag ? ep.b_diag : W)) : (ep.bias ? ep.bias : W)) + ec;
     float a[B6 ? 1 : KH];
     constexpr int NF = (B6 && !STREAM) ? KS : 1;
     u32x4 ah[NF], am[NF], al[NF];   // B6: the lane's B fragments, k = 16 ks + 8 half + (0..7)
@@ -197,18 +214,21 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
     }
     const float* wl = w_lds + half * KH * C + j;
     const u32x4* wq = reinterpret_cast<const u32x4*>(w_lds) + (j * 2 + half);   // B6: + ((plane * KS + ks) * C + n0) * 2
-    // addends: TG == 1 requests a tile's addends in front of its own MFMA loop (one buffer); TG > 1 requests them one
-    // tile ahead (two buffers)
+    // addends are requested one tile ahead (two buffers), BEFORE the current tile's stores: a load issued behind a store
+    // completes behind it
     Addend cur, nxt;
-    if (TG > 1) fetch_addend<MODE>(cur, rm, ep.yn, has_res, 0);
+    fetch_addend<MODE>(cur, rm, ep.yn, has_res, 0);
     for (int n0 = 0; n0 < C; n0 += 32 * TG) {
-      if (TG == 1) fetch_addend<MODE>(cur, rm, ep.yn, has_res, n0);
       f32x16 acc[TG];
 #pragma unroll
       for (int t = 0; t < TG; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       if constexpr (STREAM) {
+        // one step ahead.  Measured and dropped: a ring of 2 / 4 / 6 steps in flight (5.5 / 5.1 / 3.3 ms against 3.1-3.4:
+        // fragment-shaped loads touch every 128-byte line four times and more rows in flight evict them from L1 between
+        // the visits) and whole-line loads staged through the result image (9.7 ms: two fenced LDS round trips per chunk
+        // at 2 waves per SIMD)
         const float* ap = A + row * lda + 8 * half;
         float4 r0 = *reinterpret_cast<const float4*>(ap), r1 = *reinterpret_cast<const float4*>(ap + 4);
 #pragma unroll 2
@@ -263,7 +283,7 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       for (int t = 0; t < TG; ++t) {
         // request the next tile's addends (this group or the first tile of the next group) before finishing this one
         const int ncol = (t + 1 < TG) ? n0 + 32 * (t + 1) : n0 + 32 * TG;
-        if (TG > 1 && ncol < C) fetch_addend<MODE>(nxt, rm, ep.yn, has_res, ncol);
+        if (ncol < C) fetch_addend<MODE>(nxt, rm, ep.yn, has_res, ncol);
         const int col0 = n0 + 32 * t;
         gemm_wave_fence();
 #pragma unroll
@@ -278,9 +298,8 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
           float4 v = *reinterpret_cast<const float4*>(img + (8 * i + er) * OS + ec);
           const int kd = rm[i].kd;
           if (MODE == 1) {
-            const float* pb = kd == 2 ? ep.b_off : ep.b_diag;
-            const float mb = (kd > 0 && pb) ? 1.f : 0.f;
-            const float4 bb = *reinterpret_cast<const float4*>((pb ? pb + ec : pb_any) + col0);
+            const float mb = kd > 0 ? 1.f : 0.f;
+            const float4 bb = *reinterpret_cast<const float4*>(b_lds + (kd == 2 ? C : 0) + col0 + ec);
             const float m1 = kd > 0 ? 1.f : 0.f, m2 = kd == 2 ? 1.f : 0.f;
             v.x = fmaf(mb, bb.x, fmaf(m2, cur.w[i].x, fmaf(m1, cur.u[i].x, v.x)));
             v.y = fmaf(mb, bb.y, fmaf(m2, cur.w[i].y, fmaf(m1, cur.u[i].y, v.y)));
@@ -288,12 +307,12 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
             v.w = fmaf(mb, bb.w, fmaf(m2, cur.w[i].w, fmaf(m1, cur.u[i].w, v.w)));
           } else {
             if (ep.bias) {
-              const float4 bb = *reinterpret_cast<const float4*>(pb_any + col0);
+              const float4 bb = *reinterpret_cast<const float4*>(b_lds + col0 + ec);
               v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
             }
             if (has_res) { v.x += cur.u[i].x; v.y += cur.u[i].y; v.z += cur.u[i].z; v.w += cur.u[i].w; }
           }
-          if ((MODE == 1 ? kd >= 0 : kd != 0) && ep.out_bf16) {
+          if (OB && (FULL || (MODE == 1 ? kd >= 0 : kd != 0))) {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
             typedef float f2v __attribute__((ext_vector_type(2)));
             const bf16x2 lo2 = __builtin_convertvector((f2v){v.x, v.y}, bf16x2), hi2 = __builtin_convertvector((f2v){v.z, v.w}, bf16x2);
@@ -301,7 +320,7 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
             u.x = __builtin_bit_cast(uint32_t, lo2);
             u.y = __builtin_bit_cast(uint32_t, hi2);
             *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(Y) + (row0 + 8 * i + er) * ldy + col0 + ec) = u;
-          } else if (MODE == 1 ? kd >= 0 : kd != 0) {
+          } else if (!OB && (FULL || (MODE == 1 ? kd >= 0 : kd != 0))) {
             float4* yp = reinterpret_cast<float4*>(Y + (row0 + 8 * i + er) * ldy + col0 + ec);
 #ifdef HOTK_GEMM_NT   /* nontemporal result stores: measured within noise at 10 M rows (entry GEMM 5.07 vs 4.88 ms, the others +-1 %) */
             typedef float f4 __attribute__((ext_vector_type(4)));
@@ -312,30 +331,47 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
 #endif
           }
         }
-        if (TG > 1) cur = nxt;
+        cur = nxt;
       }
     }
+    };
+    if (row0 + 32 <= R) row_tile(std::true_type{});
+    else row_tile(std::false_type{});
   }
 }
 
-template <int KH, int TG, int MODE, int NW = 8, bool B6 = false>
-int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
-           hipStream_t st) {
+template <int KH, int TG, int MODE, int NW, bool B6, bool RES, bool OB>
+int launch_v(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
+             hipStream_t st) {
   constexpr int WAVES = NW;
-  const size_t lds = ((size_t)(B6 ? 3 : 2) * KH * C + (size_t)WAVES * 32 * OS) * sizeof(float);
+  const size_t lds = ((size_t)(B6 ? 3 : 2) * KH * C + (size_t)WAVES * 32 * OS + 2 * (size_t)C) * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit of a kernel is a per-process property of the function
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW, B6, RES, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
   }
   const int64_t n_tiles = (R + 32 * WAVES - 1) / (32 * WAVES);
   // persistent workgroups: two per CU where the weight and the result images allow it
-  const int per_cu = lds <= 78 * 1024 ? 2 : 1;
+  const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
-  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW, B6>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
+  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW, B6, RES, OB>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
   return hotk_launch_status();
+}
+
+// the variants in use: a residual only with MODE 0, bf16 results only from the entry GEMM (MODE 1)
+template <int KH, int TG, int MODE, int NW = 8, bool B6 = false>
+int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
+           hipStream_t st) {
+  if constexpr (MODE == 0) {
+    if (ep.out_bf16) return HOTK_EUNSUPPORTED;
+    return ep.res ? launch_v<KH, TG, MODE, NW, B6, true, false>(A, lda, W, Y, ldy, R, C, ep, st)
+                  : launch_v<KH, TG, MODE, NW, B6, false, false>(A, lda, W, Y, ldy, R, C, ep, st);
+  } else {
+    return ep.out_bf16 ? launch_v<KH, TG, MODE, NW, B6, false, true>(A, lda, W, Y, ldy, R, C, ep, st)
+                       : launch_v<KH, TG, MODE, NW, B6, false, false>(A, lda, W, Y, ldy, R, C, ep, st);
+  }
 }
 
 bool gemm_f32() {
@@ -356,11 +392,11 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
   if (K == 64 && C % 96 == 0) {
     if (MODE == 1) {
       // the split-bf16 form when its three weight planes fit in LDS beside the result images (HOTK_GEMM_F32=1: A/B runs)
-      const bool b6 = !gemm_f32() && ((size_t)3 * 32 * C + (size_t)HOTK_ENTRY_WAVES * 32 * OS) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+      const bool b6 = !gemm_f32() && ((size_t)3 * 32 * C + (size_t)HOTK_ENTRY_WAVES * 32 * OS + 2 * (size_t)C) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
       return b6 ? launch<32, 1, MODE, HOTK_ENTRY_WAVES, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
                 : launch<32, 1, MODE, HOTK_ENTRY_WAVES>(A, lda, W, Y, ldy, R, (int)C, ep, st);
     }
-    const bool b6m0 = !gemm_f32() && ((size_t)3 * 32 * C + (size_t)8 * 32 * OS) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+    const bool b6m0 = !gemm_f32() && ((size_t)3 * 32 * C + (size_t)8 * 32 * OS + 2 * (size_t)C) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
     return b6m0 ? launch<32, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
                 : launch<32, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   }
@@ -369,9 +405,11 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
     return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   }
   // wide input, narrow output: split-bf16 form while the three weight planes fit in LDS beside the result images
-  const bool b6_fits = !gemm_f32() && ((size_t)3 * (K / 2) * C + (size_t)8 * 32 * OS) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+  const bool b6_fits = !gemm_f32() && ((size_t)3 * (K / 2) * C + (size_t)8 * 32 * OS + 2 * (size_t)C) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
   if (K == 288 && C % 64 == 0) return b6_fits ? launch<144, 2, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
                                               : launch<144, 2, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
+  const bool b6_fits16 = !gemm_f32() && ((size_t)3 * (K / 2) * C + (size_t)16 * 32 * OS + 2 * (size_t)C) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+  if (K == 320 && C % 32 == 0 && b6_fits16 && HOTK_WIDE_WAVES == 16) return launch<160, 1, MODE, 16, true>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   if (K == 320 && C % 32 == 0) return b6_fits ? launch<160, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
                                               : launch<160, 1, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   return HOTK_EUNSUPPORTED;
@@ -380,7 +418,7 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
 bool shape_ok(int64_t K, int64_t C) {
   const bool known = (K == 64 && C % 96 == 0) || (K == 32 && C % 160 == 0) || (K == 288 && C % 64 == 0) ||
                      (K == 320 && C % 32 == 0);
-  return known && (K * C + MAX_WAVES * 32 * OS) * (int64_t)sizeof(float) <= 150 * 1024;
+  return known && (K * C + MAX_WAVES * 32 * OS + 2 * C) * (int64_t)sizeof(float) <= 150 * 1024;
 }
 
 }  // namespace
