@@ -225,10 +225,10 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
       if constexpr (STREAM) {
-        // one step ahead.  Measured and dropped: a ring of 2 / 4 / 6 steps in flight (5.5 / 5.1 / 3.3 ms against 3.1-3.4:
-        // fragment-shaped loads touch every 128-byte line four times and more rows in flight evict them from L1 between
-        // the visits) and whole-line loads staged through the result image (9.7 ms: two fenced LDS round trips per chunk
-        // at 2 waves per SIMD)
+        // One step ahead.  At K = 320 -> 32 with a residual the kernel moves 15.4 GB in 3.1-3.4 ms (4.5-5 TB/s): it is near the
+        // streaming ceiling, and every deeper or wider form of the row stream measured slower -- 8-k pieces 2 / 4 / 6
+        // steps ahead 5.5 / 5.1 / 3.3 ms, a lane's 64 contiguous bytes of each line two lines ahead (k order permuted
+        // in the weight planes) 3.65 ms, whole lines staged through the result image 9.7 ms.
         const float* ap = A + row * lda + 8 * half;
         float4 r0 = *reinterpret_cast<const float4*>(ap), r1 = *reinterpret_cast<const float4*>(ap + 4);
 #pragma unroll 2
@@ -335,7 +335,8 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       }
     }
     };
-    if (row0 + 32 <= R) row_tile(std::true_type{});
+    // (the wide-input kernels have one store group per row tile and nothing to gain from a second copy)
+    if (!STREAM && row0 + 32 <= R) row_tile(std::true_type{});
     else row_tile(std::false_type{});
   }
 }
