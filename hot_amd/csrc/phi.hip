@@ -348,6 +348,146 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_bwd(const float* __
   }
 }
 
+// The softmax maps for head widths 8 / 16 / 32 with 16-byte aligned rows, as row-walking kernels like the ReLU ones
+// above (the thread-per-(row, head) kernels write a head's m features as m stores 4 m bytes apart and recompute all m
+// pre-activations in every one of a head's d backward threads).  Same fmaf chains, same maximum / summation order:
+// identical bits.
+constexpr int PHI_SM_MAXF = 4096;      // HH m floats of pre-activations per row held in LDS by the forward kernel
+template <int D>
+__device__ __forceinline__ float head_half_sqnorm(const float* __restrict__ xs, float scale) {
+  float nrm = 0.f;
+#pragma unroll
+  for (int q = 0; q < D / 4; ++q) {
+    const float4 v = *reinterpret_cast<const float4*>(xs + 4 * q);
+    nrm = fmaf(v.x, v.x, nrm); nrm = fmaf(v.y, v.y, nrm); nrm = fmaf(v.z, v.z, nrm); nrm = fmaf(v.w, v.w, nrm);
+  }
+  return nrm * 0.5f * scale * scale;
+}
+
+// forward: a block walks rows, a thread takes features f, f + 256, ...; the pre-activations of the row meet in LDS so
+// that a query feature finds the maximum of its head (scanned in feature order, as the reference loop does)
+template <int D>
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_fwd_d(const float* __restrict__ x, int64_t ld_x,
+                                                                   const float* __restrict__ proj,
+                                                                   const uint8_t* __restrict__ kind, unsigned keep,
+                                                                   float* __restrict__ phi, int64_t ld_phi, int64_t n,
+                                                                   int HH, int m, float scale, float eps, float ratio,
+                                                                   int mode, const float* __restrict__ gstat) {
+  __shared__ float P[PHI_MAX_M * (D + 1)];
+  __shared__ float pre_s[PHI_SM_MAXF];
+  stage_proj_padded<D>(P, proj, m);
+  const int F = HH * m;
+  const bool qmode = mode == HOTK_PHI_SOFTMAX_Q;
+  const float gmax = qmode ? 0.f : gstat[0];
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const bool on = !kind || hotk_keep(keep, kind[r]);      // block-uniform
+    const float* xr = x + r * ld_x;
+    float* pr = phi + r * ld_phi;
+    if (!on) {
+      for (int f = threadIdx.x; f < F; f += PHI_THREADS) pr[f] = 0.f;
+      continue;
+    }
+    for (int f = threadIdx.x; f < F; f += PHI_THREADS) {
+      const int hh = f / m, mm = f - hh * m;
+      pre_s[f] = proj_dot_v<D>(xr + hh * D, P + mm * (D + 1), scale);
+    }
+    if (qmode) __syncthreads();
+    for (int f = threadIdx.x; f < F; f += PHI_THREADS) {
+      const int hh = f / m;
+      float stab = gmax;
+      if (qmode) {
+        stab = -INFINITY;
+        const float* ph = pre_s + hh * m;
+        for (int j = 0; j < m; ++j) stab = fmaxf(stab, ph[j]);
+      }
+      const float diag = head_half_sqnorm<D>(xr + hh * D, scale);
+      pr[f] = ratio * (expf(pre_s[f] - diag - stab) + eps);
+    }
+    if (qmode) __syncthreads();      // the next row overwrites pre_s
+  }
+}
+
+// backward: thread (head-slot, k) like k_phi_relu_bwd_d.  Phase A: the head's pre-activations (thread k: features k,
+// k + D, ...) -> LDS; phase B: a[mm] = g ratio exp(pre - diag - stab) and, for the key map, the share of the global
+// maximum's gradient -> LDS; phase C: thread k contracts with column k of the projection in feature order.
+template <int D>
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_softmax_bwd_d(const float* __restrict__ x, int64_t ld_x,
+                                                                   const float* __restrict__ proj,
+                                                                   const uint8_t* __restrict__ kind, unsigned keep,
+                                                                   const float* __restrict__ dphi, int64_t ld_dphi,
+                                                                   float* __restrict__ dx, int64_t ld_dx, int64_t n,
+                                                                   int HH, int m, float scale, float ratio, int mode,
+                                                                   const float* __restrict__ gstat) {
+  constexpr int SLOTS = PHI_THREADS / D;
+  __shared__ float P[PHI_MAX_M * (D + 1)];
+  __shared__ float pre_s[SLOTS * PHI_MAX_M];
+  __shared__ float a_s[SLOTS * PHI_MAX_M];
+  stage_proj_padded<D>(P, proj, m);
+  const int C = HH * D;
+  const int k = threadIdx.x % D, slot = threadIdx.x / D;
+  float* pre = pre_s + slot * m;
+  float* av = a_s + slot * m;
+  const bool qmode = mode == HOTK_PHI_SOFTMAX_Q;
+  float gmax = 0.f, gshare = 0.f, wrep = 1.f;
+  if (!qmode) {
+    gmax = gstat[0];
+    gshare = gstat[1] / fmaxf(gstat[2], 1e-30f);
+    if (gstat[3] > 0.f) wrep = gstat[3];
+  }
+  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
+    const bool live = !kind || hotk_keep(keep, kind[r]);
+    const float wr = (kind && kind[r] == 2) ? 1.f : wrep;
+    const float* xr = x + r * ld_x;
+    const float* gr = dphi + r * ld_dphi;
+    for (int c0 = 0; c0 < C; c0 += PHI_THREADS) {   // block-uniform trip count: the barriers below are reached by all
+      const int c = c0 + threadIdx.x, hh = c / D;
+      const bool act = c < C;
+      if (act)
+        for (int mm = k; mm < m; mm += D) pre[mm] = proj_dot_v<D>(xr + hh * D, P + mm * (D + 1), scale);
+      __syncthreads();
+      float stab = gmax, diag = 0.f;
+      int arg = 0;
+      if (act) {
+        diag = head_half_sqnorm<D>(xr + hh * D, scale);
+        if (qmode) {
+          stab = -INFINITY;
+          for (int mm = 0; mm < m; ++mm)
+            if (pre[mm] > stab) { stab = pre[mm]; arg = mm; }
+        }
+        for (int mm = k; mm < m; mm += D) av[mm] = live ? gr[hh * m + mm] * ratio * expf(pre[mm] - diag - stab) : 0.f;
+      }
+      __syncthreads();
+      if (act) {
+        float acc = 0.f, asum = 0.f;
+        if (qmode) {
+          if (live) {
+            for (int mm = 0; mm < m; ++mm) {
+              const float a = av[mm];
+              asum += a;
+              acc = fmaf(a, P[mm * (D + 1) + k], acc);
+            }
+            acc -= asum * P[arg * (D + 1) + k];
+          }
+        } else {
+          for (int mm = 0; mm < m; ++mm) {
+            const float a = av[mm];
+            asum += a;
+            const float dpre = a - ((pre[mm] == gmax) ? gshare * wr : 0.f);
+            acc = fmaf(dpre, P[mm * (D + 1) + k], acc);
+          }
+        }
+        dx[r * ld_dx + c] = scale * acc - asum * scale * scale * xr[c];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+bool phi_softmax_vec_ok(const float* x, int64_t ld_x, int HH, int d, int m) {
+  return (d == 8 || d == 16 || d == 32) && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0 && m <= PHI_MAX_M &&
+         (int64_t)HH * m <= PHI_SM_MAXF;
+}
+
 // ------------------------------------------------------------------ global statistics for the key branch
 __device__ __forceinline__ float block_reduce_max(float v, float* lds) {
 #pragma unroll
@@ -491,6 +631,14 @@ extern "C" int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, con
   } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_fwd, dim3(hotk_grid(n * HH * m, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, phi, ld_phi, n, HH, d, m, scale, 1e-3f);
+  } else if (phi_softmax_vec_ok(x, ld_x, HH, d, m)) {
+    const dim3 grid(hotk_grid(n, 1, 256 * 32)), block(PHI_THREADS);
+    const float ratio = 1.0f / sqrtf((float)m);
+    switch (d) {
+      case 8: hipLaunchKernelGGL(k_phi_softmax_fwd_d<8>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-4f, ratio, mode, gstat); break;
+      case 16: hipLaunchKernelGGL(k_phi_softmax_fwd_d<16>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-4f, ratio, mode, gstat); break;
+      default: hipLaunchKernelGGL(k_phi_softmax_fwd_d<32>, grid, block, 0, st, x, ld_x, proj, kind, keep, phi, ld_phi, n, HH, m, scale, 1e-4f, ratio, mode, gstat);
+    }
   } else {
     hipLaunchKernelGGL(k_phi_softmax_fwd, dim3(hotk_grid(n * HH, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, phi, ld_phi, n, HH, d, m, scale, 1e-4f, 1.0f / sqrtf((float)m), mode, gstat);
@@ -523,6 +671,14 @@ extern "C" int hotk_phi_bwd(const float* x, int64_t ld_x, const float* proj, con
   } else if (mode == HOTK_PHI_RELU) {
     hipLaunchKernelGGL(k_phi_relu_bwd, dim3(hotk_grid(n * HH * d, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x, proj,
                        kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, d, m, scale);
+  } else if (phi_softmax_vec_ok(x, ld_x, HH, d, m)) {
+    const dim3 grid(hotk_grid(n, 1, 256 * 32)), block(PHI_THREADS);
+    const float ratio = 1.0f / sqrtf((float)m);
+    switch (d) {
+      case 8: hipLaunchKernelGGL(k_phi_softmax_bwd_d<8>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale, ratio, mode, gstat); break;
+      case 16: hipLaunchKernelGGL(k_phi_softmax_bwd_d<16>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale, ratio, mode, gstat); break;
+      default: hipLaunchKernelGGL(k_phi_softmax_bwd_d<32>, grid, block, 0, st, x, ld_x, proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, m, scale, ratio, mode, gstat);
+    }
   } else {
     hipLaunchKernelGGL(k_phi_softmax_bwd, dim3(hotk_grid(n * HH * d, PHI_THREADS)), dim3(PHI_THREADS), 0, st, x, ld_x,
                        proj, kind, keep, dphi, ld_dphi, dx, ld_dx, n, HH, d, m, scale, 1.0f / sqrtf((float)m), mode,
