@@ -53,9 +53,9 @@ _SIGNATURES = {
     'hotk_phi_key_stats': [_P, _L, _P, _L, _I, _I, _I, _P, _P, _S, _P],
     'hotk_phi_key_bwd_stats': [_P, _L, _P, _P, _U, _P, _L, _L, _I, _I, _I, _P, _P, _S, _P],
     'hotk_seg_outer_sum': [_P, _L, _P, _P, _L, _P, _P, _L, _P, _P, _P, _P, _L, _I, _I, _I, _L, _P],
-    'hotk_row_contract': [_P, _L, _P, _P, _P, _L, _P, _U, _P, _P, _L, _L, _I, _I, _I, _I, _P],
-    'hotk_apply_bwd_stats': [_P, _L, _P, _P, _L, _P, _U, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P],
-    'hotk_row_expand': [_P, _P, _L, _P, _L, _P, _P, _L, _P, _U, _P, _L, _L, _I, _I, _I, _P],
+    'hotk_row_contract': [_P, _L, _P, _P, _P, _L, _P, _U, _P, _P, _L, _L, _I, _I, _I, _I, _P, _P],
+    'hotk_apply_bwd_stats': [_P, _L, _P, _P, _L, _P, _U, _P, _L, _P, _L, _P, _L, _L, _I, _I, _I, _P, _P],
+    'hotk_row_expand': [_P, _P, _L, _P, _L, _P, _P, _L, _P, _U, _P, _L, _L, _I, _I, _I, _P, _P],
 }
 
 

@@ -84,13 +84,14 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_contract(
     const float* __restrict__ Q, int64_t ld_q, const int32_t* __restrict__ qidx, const float* __restrict__ KV,
     const int32_t* __restrict__ sidx, int64_t seg_div, const uint8_t* __restrict__ kind, unsigned keep,
     const int32_t* __restrict__ oidx, float* __restrict__ out, int64_t ld_out, int64_t n, int HH, int m, int c,
-    int normalize) {
+    int normalize, const int32_t* __restrict__ order) {
   const int F = HH * m, c1 = c + 1, W = HH * c;
   const int64_t total = n * W;
   const bool q4 = (m & 3) == 0 && (ld_q & 3) == 0 && (((uintptr_t)Q) & 15u) == 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = t / W;
-    int w = (int)(t - r * W);
+    const int64_t pos = t / W;
+    int w = (int)(t - pos * W);
+    const int64_t r = order ? (int64_t)order[pos] : pos;
     int hh = w / c, chn = w - hh * c;
     int64_t orow = oidx ? (int64_t)oidx[r] : r;
     if (orow < 0) continue;
@@ -132,12 +133,14 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_contract(
 __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats(
     const float* __restrict__ Q, int64_t ld_q, const float* __restrict__ KV, const int32_t* __restrict__ sidx,
     int64_t seg_div, const uint8_t* __restrict__ kind, unsigned keep, const float* __restrict__ dO, int64_t ld_do,
-    float* __restrict__ X, int64_t ld_x, float* __restrict__ XA, int64_t ld_xa, int64_t n, int HH, int m, int c) {
+    float* __restrict__ X, int64_t ld_x, float* __restrict__ XA, int64_t ld_xa, int64_t n, int HH, int m, int c,
+    const int32_t* __restrict__ order) {
   const int F = HH * m, c1 = c + 1;
   const int64_t total = n * HH;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = t / HH;
-    int hh = (int)(t - r * HH);
+    const int64_t pos = t / HH;
+    int hh = (int)(t - pos * HH);
+    const int64_t r = order ? (int64_t)order[pos] : pos;
     float* xo = X + r * ld_x + hh * c;
     int64_t s = seg_of(sidx, seg_div, r);
     if (s < 0 || (kind && !hotk_keep(keep, kind[r]))) {
@@ -173,7 +176,8 @@ template <int C>
 __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
     const float* __restrict__ Q, int64_t ld_q, const float* __restrict__ KV, const int32_t* __restrict__ sidx,
     int64_t seg_div, const uint8_t* __restrict__ kind, unsigned keep, const float* __restrict__ dO, int64_t ld_do,
-    float* __restrict__ X, int64_t ld_x, float* __restrict__ XA, int64_t ld_xa, int64_t n, int HH, int m) {
+    float* __restrict__ X, int64_t ld_x, float* __restrict__ XA, int64_t ld_xa, int64_t n, int HH, int m,
+    const int32_t* __restrict__ order) {
   constexpr int c1 = C + 1;
   const int F = HH * m, W = HH * C;
   const int64_t total = n * W;
@@ -182,8 +186,9 @@ __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
   const bool q4 = (m & 3) == 0 && (ld_q & 3) == 0 && (((uintptr_t)Q) & 15u) == 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < padded; t += (int64_t)gridDim.x * blockDim.x) {
     const bool live = t < total;
-    const int64_t r = live ? t / W : 0;
-    const int w = (int)(t - r * W);
+    const int64_t pos = live ? t / W : 0;
+    const int w = (int)(t - pos * W);
+    const int64_t r = (live && order) ? (int64_t)order[pos] : pos;
     const int hh = live ? w / C : 0, chn = w - hh * C;
     const int64_t s = live ? seg_of(sidx, seg_div, r) : -1;
     const bool on = live && s >= 0 && (!kind || hotk_keep(keep, kind[r]));
@@ -230,13 +235,14 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
     const float* __restrict__ KV, const int32_t* __restrict__ sidx, int64_t seg_div, const float* __restrict__ X,
     int64_t ld_x, const int32_t* __restrict__ xidx, const float* __restrict__ XA, int64_t ld_xa,
     const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out, int64_t ld_out, int64_t n, int HH, int m,
-    int c) {
+    int c, const int32_t* __restrict__ order) {
   const int F = HH * m, c1 = c + 1;
   const int64_t total = n * F;
   const bool x8 = c == 8 && (ld_x & 3) == 0 && (((uintptr_t)X) & 15u) == 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    int64_t r = t / F;
-    int f = (int)(t - r * F);
+    const int64_t pos = t / F;
+    int f = (int)(t - pos * F);
+    const int64_t r = order ? (int64_t)order[pos] : pos;
     int hh = f / m;
     float o = 0.f;
     int64_t s = seg_of(sidx, seg_div, r);
@@ -274,7 +280,8 @@ template <int C>
 __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
     const float* __restrict__ KV, const int32_t* __restrict__ sidx, int64_t seg_div, const float* __restrict__ X,
     int64_t ld_x, const int32_t* __restrict__ xidx, const float* __restrict__ XA, int64_t ld_xa,
-    const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out, int64_t ld_out, int64_t n, int HH, int m) {
+    const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out, int64_t ld_out, int64_t n, int HH, int m,
+    const int32_t* __restrict__ order) {
   constexpr int c1 = C + 1;
   __shared__ float img_all[RX_WAVES][64 * c1];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -292,6 +299,7 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
     const int hh = (lane < nf ? f : f0) / m;
     const int64_t r0 = ch * RX_ROWS, r1 = r0 + RX_ROWS < n ? r0 + RX_ROWS : n;
     // the segment of row r, or -1 when the row's output is zero (wave-uniform)
+    auto rowid = [&](int64_t pos) -> int64_t { return order ? (int64_t)order[pos] : pos; };
     auto seg_on = [&](int64_t r) -> int64_t {
       const int64_t sg = seg_of(sidx, seg_div, r);
       return (sg >= 0 && (!kind || hotk_keep(keep, kind[r]))) ? sg : -1;
@@ -299,7 +307,8 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
     float kv[c1], pre[c1];
 #pragma unroll
     for (int k = 0; k < c1; ++k) kv[k] = pre[k] = 0.f;
-    int64_t s_cur = -1, s_nxt = seg_on(r0);
+    int64_t r_nxt = rowid(r0);
+    int64_t s_cur = -1, s_nxt = seg_on(r_nxt);
     auto fetch = [&](int64_t sg) {          // the block's 64 (c + 1) floats, coalesced, into registers
       const float* blk = KV + (sg * F + f0) * c1;
 #pragma unroll
@@ -309,7 +318,8 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
       }
     };
     if (s_nxt >= 0) fetch(s_nxt);
-    for (int64_t r = r0; r < r1; ++r) {
+    for (int64_t pos = r0; pos < r1; ++pos) {
+      const int64_t r = r_nxt;
       const int64_t sg = s_nxt;
       if (sg >= 0 && sg != s_cur) {         // transpose through the wave's LDS image: lane <- row lane of the block
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -339,8 +349,9 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
         }
         if (XA) xa = XA[r * ld_xa + hh];
       }
-      if (r + 1 < r1) {
-        s_nxt = seg_on(r + 1);
+      if (pos + 1 < r1) {
+        r_nxt = rowid(pos + 1);
+        s_nxt = seg_on(r_nxt);
         if (s_nxt >= 0 && s_nxt != s_cur) fetch(s_nxt);
       }
       float o = 0.f;
@@ -470,20 +481,20 @@ extern "C" int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* k
 extern "C" int hotk_row_contract(const float* Q, int64_t ld_q, const int32_t* qidx, const float* KV,
                                  const int32_t* sidx, int64_t seg_div, const uint8_t* kind, unsigned keep,
                                  const int32_t* oidx, float* out, int64_t ld_out, int64_t n, int HH, int m, int c,
-                                 int normalize, void* stream) {
+                                 int normalize, const int32_t* order, void* stream) {
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(Q && KV && out && ld_q >= (int64_t)HH * m && ld_out >= (int64_t)HH * c);
   hipLaunchKernelGGL(k_row_contract, dim3(hotk_grid(n * HH * c, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
                      (hipStream_t)stream, Q, ld_q, qidx, KV, sidx, seg_div, kind, keep, oidx, out, ld_out, n, HH, m, c,
-                     normalize);
+                     normalize, order);
   return hotk_launch_status();
 }
 
 extern "C" int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* KV, const int32_t* sidx,
                                     int64_t seg_div, const uint8_t* kind, unsigned keep, const float* dO, int64_t ld_do,
                                     float* X, int64_t ld_x, float* XA, int64_t ld_xa, int64_t n, int HH, int m, int c,
-                                    void* stream) {
+                                    const int32_t* order, void* stream) {
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(Q && KV && dO && X && XA && ld_q >= (int64_t)HH * m && ld_do >= (int64_t)HH * c &&
@@ -492,14 +503,14 @@ extern "C" int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* K
 #define HOTK_ABS_CASE(CC)                                                                                              \
   case CC:                                                                                                             \
     hipLaunchKernelGGL(k_apply_bwd_stats_c<CC>, dim3(hotk_grid(n * HH * CC, AT_THREADS, 256 * 32)), dim3(AT_THREADS),  \
-                       0, st, Q, ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH, m);        \
+                       0, st, Q, ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH, m, order); \
     break;
   switch (c) {
     HOTK_ABS_CASE(1) HOTK_ABS_CASE(2) HOTK_ABS_CASE(4) HOTK_ABS_CASE(8) HOTK_ABS_CASE(16) HOTK_ABS_CASE(32)
     HOTK_ABS_CASE(64)
     default:
       hipLaunchKernelGGL(k_apply_bwd_stats, dim3(hotk_grid(n * HH, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0, st, Q,
-                         ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH, m, c);
+                         ld_q, KV, sidx, seg_div, kind, keep, dO, ld_do, X, ld_x, XA, ld_xa, n, HH, m, c, order);
   }
 #undef HOTK_ABS_CASE
   return hotk_launch_status();
@@ -507,7 +518,8 @@ extern "C" int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* K
 
 extern "C" int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const float* X, int64_t ld_x,
                                const int32_t* xidx, const float* XA, int64_t ld_xa, const uint8_t* kind, unsigned keep,
-                               float* out, int64_t ld_out, int64_t n, int HH, int m, int c, void* stream) {
+                               float* out, int64_t ld_out, int64_t n, int HH, int m, int c, const int32_t* order,
+                               void* stream) {
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(KV && X && out && ld_x >= (int64_t)HH * c && ld_out >= (int64_t)HH * m && (!XA || ld_xa >= HH));
@@ -516,14 +528,14 @@ extern "C" int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg
     const dim3 grid(hotk_grid(items, RX_WAVES, 256 * 32)), block(64 * RX_WAVES);
     if (c == 16)
       hipLaunchKernelGGL(k_row_expand_w<16>, grid, block, 0, (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA,
-                         ld_xa, kind, keep, out, ld_out, n, HH, m);
+                         ld_xa, kind, keep, out, ld_out, n, HH, m, order);
     else
       hipLaunchKernelGGL(k_row_expand_w<8>, grid, block, 0, (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA,
-                         ld_xa, kind, keep, out, ld_out, n, HH, m);
+                         ld_xa, kind, keep, out, ld_out, n, HH, m, order);
     return hotk_launch_status();
   }
   hipLaunchKernelGGL(k_row_expand, dim3(hotk_grid(n * HH * m, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
                      (hipStream_t)stream, KV, sidx, seg_div, X, ld_x, xidx, XA, ld_xa, kind, keep, out, ld_out, n, HH,
-                     m, c);
+                     m, c, order);
   return hotk_launch_status();
 }

@@ -135,38 +135,49 @@ def seg_outer_sum(K, kidx, V, vidx, aug, seg, HH, m, c):
     return KV
 
 
-def row_contract(Q, qidx, KV, sidx, seg_div, kind, keep, n, HH, m, c, normalize, oidx=None, n_out=None):
+def _visit(order, n):
+    """(order, rows visited, allocator): an order that lists fewer than n rows leaves the others untouched -> zeros"""
+    if order is None:
+        return None, n, torch.empty
+    return order, order.numel(), (torch.empty if order.numel() == n else torch.zeros)
+
+
+def row_contract(Q, qidx, KV, sidx, seg_div, kind, keep, n, HH, m, c, normalize, oidx=None, n_out=None, order=None):
     q, ldq, _, Cq = rows2d(Q)
     assert Cq == HH * m
     n_out = n if n_out is None else n_out
-    alloc = torch.zeros if oidx is not None else torch.empty
+    order, nv, alloc = _visit(order, n)
+    if oidx is not None:
+        alloc = torch.zeros
     out = alloc(n_out, HH * c, dtype=Q.dtype, device=Q.device)
-    call('hotk_row_contract', 4 * n * HH * (m + c) + 4 * KV.numel(), p(q), ldq, p(qidx), p(KV), p(sidx), seg_div, p(kind), keep, p(oidx), p(out), HH * c, n,
-                                  HH, m, c, int(normalize))
+    call('hotk_row_contract', 4 * nv * HH * (m + c) + 4 * KV.numel(), p(q), ldq, p(qidx), p(KV), p(sidx), seg_div, p(kind), keep, p(oidx), p(out), HH * c, nv,
+                                  HH, m, c, int(normalize), p(order))
     return out
 
 
-def apply_bwd_stats(Q, KV, sidx, seg_div, kind, keep, dO, n, HH, m, c):
+def apply_bwd_stats(Q, KV, sidx, seg_div, kind, keep, dO, n, HH, m, c, order=None):
     q, ldq, _, _ = rows2d(Q)
     g, ldg, ng, Cg = rows2d(dO)
     assert ng == n and Cg == HH * c
-    X = torch.empty(n, HH * c, dtype=Q.dtype, device=Q.device)
-    XA = torch.empty(n, HH, dtype=Q.dtype, device=Q.device)
-    call('hotk_apply_bwd_stats', 4 * n * HH * (m + 2 * c + 1) + 4 * KV.numel(), p(q), ldq, p(KV), p(sidx), seg_div, p(kind), keep, p(g), ldg, p(X), HH * c, p(XA), HH,
-                                     n, HH, m, c)
+    order, nv, alloc = _visit(order, n)
+    X = alloc(n, HH * c, dtype=Q.dtype, device=Q.device)
+    XA = alloc(n, HH, dtype=Q.dtype, device=Q.device)
+    call('hotk_apply_bwd_stats', 4 * nv * HH * (m + 2 * c + 1) + 4 * KV.numel(), p(q), ldq, p(KV), p(sidx), seg_div, p(kind), keep, p(g), ldg, p(X), HH * c, p(XA), HH,
+                                     nv, HH, m, c, p(order))
     return X, XA
 
 
-def row_expand(KV, sidx, seg_div, X, xidx, XA, kind, keep, n, HH, m, c):
+def row_expand(KV, sidx, seg_div, X, xidx, XA, kind, keep, n, HH, m, c, order=None):
     x, ldx, _, Cx = rows2d(X)
     assert Cx == HH * c
     if XA is not None:
         a, lda, _, _ = rows2d(XA)
     else:
         a, lda = None, 0
-    out = torch.empty(n, HH * m, dtype=X.dtype, device=X.device)
-    call('hotk_row_expand', 4 * n * HH * (m + c) + 4 * KV.numel(), p(KV), p(sidx), seg_div, p(x), ldx, p(xidx), p(a), lda, p(kind), keep, p(out), HH * m, n,
-                                HH, m, c)
+    order, nv, alloc = _visit(order, n)
+    out = alloc(n, HH * m, dtype=X.dtype, device=X.device)
+    call('hotk_row_expand', 4 * nv * HH * (m + c) + 4 * KV.numel(), p(KV), p(sidx), seg_div, p(x), ldx, p(xidx), p(a), lda, p(kind), keep, p(out), HH * m, nv,
+                                HH, m, c, p(order))
     return out
 
 
@@ -675,6 +686,12 @@ class KernelAttn(Function):
             else:
                 sidx, seg_div = (plan.coln if dim1 == 2 else plan.rown), 1
             vsidx, vseg_div = plan.coln, 1
+        # rows keyed by their COLUMN node are visited column by column (the plan's CSR permutation), so that a node's
+        # key-value block is fetched once per node instead of once per entry (it is m (c + 1) floats per head: 24 KB at
+        # d = 16, m = 44); rows keyed by their row node are adjacent already
+        by_col = plan.col_perm[:plan.Ev] if diagonal is not None else None
+        qorder = by_col if (diagonal is not None and ord_q == 2 and diagonal[0] == 2) else None
+        vorder = by_col
         kind_q, keep_q = (plan.nkind, KEEP_DIAG) if ord_q == 1 else (plan.kind, KEEP_OFFDIAG)
         # edge-shard mode (hot_amd.dist): sums over ENTRIES are partial on each rank and are all-reduced; diagonal
         # entries are replicated on every rank and enter with weight 1/world.  Sums over nodes are replicated work.
@@ -689,9 +706,10 @@ class KernelAttn(Function):
         KV = seg_outer_sum(k, kidx, vw, None, aug, seg, HH, m, c)
         if reduce_kv:
             shard.all_reduce_(KV)
-        out = row_contract(q, None, KV, sidx, seg_div, kind_q, keep_q, nq, HH, m, c, True)
+        out = row_contract(q, None, KV, sidx, seg_div, kind_q, keep_q, nq, HH, m, c, True, order=qorder)
         ctx.save_for_backward(q, k, vw, KV, aug, wv)
         ctx.cfg = (plan, ord_q, ord_k, HH, m, c, diagonal, nq, nk, nv, kidx, sidx, seg_div, vsidx, vseg_div, kind_q, keep_q)
+        ctx.orders = (qorder, vorder)
         ctx.vshape, ctx.reduce_kv = v.shape, reduce_kv
         return out.view(*q.shape[:-1], HH * c)
 
@@ -700,8 +718,9 @@ class KernelAttn(Function):
         q, k, v, KV, aug, wv = ctx.saved_tensors
         plan, ord_q, ord_k, HH, m, c, diagonal, nq, nk, nv, kidx, sidx, seg_div, vsidx, vseg_div, kind_q, keep_q = ctx.cfg
         dO = dO.contiguous()
-        X, XA = apply_bwd_stats(q, KV, sidx, seg_div, kind_q, keep_q, dO, nq, HH, m, c)
-        dq = row_expand(KV, sidx, seg_div, X, None, XA, kind_q, keep_q, nq, HH, m, c)
+        qorder, vorder = ctx.orders
+        X, XA = apply_bwd_stats(q, KV, sidx, seg_div, kind_q, keep_q, dO, nq, HH, m, c, order=qorder)
+        dq = row_expand(KV, sidx, seg_div, X, None, XA, kind_q, keep_q, nq, HH, m, c, order=qorder)
         # dKV[s] = sum over the queries that read segment s of q (x) [dnum | dden]
         if diagonal is None:
             qseg = plan.graph_seg(ord_q)
@@ -713,10 +732,10 @@ class KernelAttn(Function):
         if ctx.reduce_kv:
             plan.shard.all_reduce_(dKV)       # backward of the forward all-reduce: every rank needs the full dKV
         kind_v = plan.nkind if (diagonal is None and ord_k == 1) else plan.kind
-        dv = row_contract(k, kidx, dKV, vsidx, vseg_div, kind_v, KEEP_VALID, nv, HH, m, c, False)
+        dv = row_contract(k, kidx, dKV, vsidx, vseg_div, kind_v, KEEP_VALID, nv, HH, m, c, False, order=vorder)
         if wv is not None:
             dv = dv * wv
-        dkc = row_expand(dKV, vsidx, vseg_div, v, None, aug, kind_v, KEEP_VALID, nv, HH, m, c)
+        dkc = row_expand(dKV, vsidx, vseg_div, v, None, aug, kind_v, KEEP_VALID, nv, HH, m, c, order=vorder)
         if diagonal is None:
             dk = dkc
         else:

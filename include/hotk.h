@@ -212,21 +212,27 @@ int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* kidx, const 
                        const int32_t* vidx, const float* aug, int64_t ld_aug, const int32_t* seg_begin,
                        const int32_t* seg_end, const int32_t* perm, float* KV, int64_t n_seg, int HH, int m,
                        int c, int64_t max_seg_len, void* stream);
+/* The three row-wise calls below take `order` (NULL = natural): the n rows are VISITED as r = order[0..n); rows that
+ * are not listed are left untouched.  With the rows of one segment adjacent in it (a CSR permutation, e.g. the plan's
+ * col_perm when sidx is the column node) a segment's [F, c+1] block is fetched once per segment instead of once per row.
+ * Results do not depend on it. */
 /* out[orow][hh*c+ch] = sum_mm Q[qidx[r]][hh*m+mm] * KV[s][hh*m+mm][ch]  (/ guard(sum_mm Q*KV[..][c]) if
  * normalize), s = sidx ? sidx[r] : r / seg_div, orow = oidx ? oidx[r] : r.  Rows with kind not in keep or
  * s < 0 write zeros (skipped when oidx is given and orow < 0). */
 int hotk_row_contract(const float* Q, int64_t ld_q, const int32_t* qidx, const float* KV, const int32_t* sidx,
                       int64_t seg_div, const uint8_t* kind, unsigned keep, const int32_t* oidx, float* out,
-                      int64_t ld_out, int64_t n, int HH, int m, int c, int normalize, void* stream);
+                      int64_t ld_out, int64_t n, int HH, int m, int c, int normalize, const int32_t* order,
+                      void* stream);
 /* backward statistics of the normalised application: X[r][hh*c+ch] = dO/den, XA[r][hh] = -(dO.O)/den
  * (0 where the 1e-5 guard was taken or the row is masked). */
 int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* KV, const int32_t* sidx, int64_t seg_div,
                          const uint8_t* kind, unsigned keep, const float* dO, int64_t ld_do, float* X,
-                         int64_t ld_x, float* XA, int64_t ld_xa, int64_t n, int HH, int m, int c, void* stream);
+                         int64_t ld_x, float* XA, int64_t ld_xa, int64_t n, int HH, int m, int c,
+                         const int32_t* order, void* stream);
 /* out[r][f] = sum_ch KV[s][f][ch] * X[xidx[r]][hh*c+ch] + KV[s][f][c] * (XA ? XA[r][hh] : 1) */
 int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg_div, const float* X, int64_t ld_x,
                     const int32_t* xidx, const float* XA, int64_t ld_xa, const uint8_t* kind, unsigned keep,
-                    float* out, int64_t ld_out, int64_t n, int HH, int m, int c, void* stream);
+                    float* out, int64_t ld_out, int64_t n, int HH, int m, int c, const int32_t* order, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Order-0 softmax readout: segmented softmax pooling with a per-segment (per-graph) query vector

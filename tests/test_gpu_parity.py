@@ -813,6 +813,17 @@ def test_general_attention_kernels_masks_and_indices(HH, m, c):
         Xin, XAin = padded(Xsrc, pad), padded(XAsrc, pad)
         E = ops.row_expand(KV, dev(sidx), 1, Xin, dev(vidx), XAin, dev(kind), _lib.KEEP_VALID, n, HH, m, c)
         E1 = ops.row_expand(KV, None, 13, Xin, None, None, None, 0, n_src, HH, m, c)     # segment = row // 13, no masks
+        # the same calls with the rows visited segment by segment (`order`): identical results
+        by_seg = torch.argsort(sidx.long(), stable=True).to(torch.int32).to(DEV)
+        assert torch.equal(O, ops.row_contract(Qd, dev(qidx), KV, dev(sidx), 1, dev(kind), _lib.KEEP_OFFDIAG, n, HH, m, c, True, order=by_seg))
+        Xo, XAo = ops.apply_bwd_stats(Qd, KV, dev(sidx), 1, dev(kind), _lib.KEEP_VALID, dOd, n, HH, m, c, order=by_seg)
+        assert torch.equal(X, Xo) and torch.equal(XA, XAo)
+        assert torch.equal(E, ops.row_expand(KV, dev(sidx), 1, Xin, dev(vidx), XAin, dev(kind), _lib.KEEP_VALID, n, HH, m, c, order=by_seg))
+        part = by_seg[: n // 2]                                                      # a partial order leaves the other rows at zero
+        Ep = ops.row_expand(KV, dev(sidx), 1, Xin, dev(vidx), XAin, dev(kind), _lib.KEEP_VALID, n, HH, m, c, order=part)
+        seen = torch.zeros(n, dtype=torch.bool, device=DEV)
+        seen[part.long()] = True
+        assert torch.equal(Ep[seen], E[seen]) and float(Ep[~seen].abs().max()) == 0.0
         outs[pad] = [t.cpu() for t in (KV, O, On, X, XA, E, E1)]
         if pad == 0:
             ins = dict(Q=Q, dO=dO, sidx=sidx, kind=kind, qidx=qidx, Xin=Xsrc, XAin=XAsrc)
