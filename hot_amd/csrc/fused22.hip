@@ -468,6 +468,63 @@ constexpr int TPB = 64 * WPB;
 __device__ __forceinline__ int64_t wave_index() {
   return (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(blockIdx.x * WPB + (threadIdx.x >> 6)));
 }
+// ---- work distribution --------------------------------------------------------------------------------------------
+// One single-wave workgroup per node leaves the chip at ~2.4 of the 4 waves per SIMD the registers allow (measured:
+// SQ_WAVE_CYCLES / GRBM_GUI_ACTIVE; 978 k workgroups of ~20 us each: slots are refilled slower than waves retire).  A
+// persistent grid with a static stride fills the slots but scatters the nodes in flight over the whole batch and loses
+// the L2 reuse between neighbouring nodes (8.1 -> 14.6 ms).  Persistent waves that draw TICKETS -- TN consecutive items
+// per atomic, in item order -- keep both: full slots and a moving window of neighbouring nodes (k_seg_bwd 8.1 -> 5.7 ms).
+// One atomic per NODE on one address would run at ~86 per microsecond (11.4 ms per kernel): hence TN items per ticket.
+// The next ticket is requested when the current one starts and read when it ends.  ticket == nullptr: static stride.
+#ifndef HOTK_DYN
+#define HOTK_DYN 1
+#endif
+#ifndef HOTK_TICKET_NODES
+#define HOTK_TICKET_NODES 8
+#endif
+#ifndef HOTK_DYN_GRID
+#define HOTK_DYN_GRID (256 * 4 * 6)   /* persistent workgroups: 6 per SIMD cover every register budget of these kernels */
+#endif
+template <int TN>
+struct WorkIter {
+  unsigned* t;
+  int64_t total, cur, end;
+  unsigned tv;
+  __device__ __forceinline__ WorkIter(unsigned* __restrict__ ticket, int64_t n_items) : t(ticket), total(n_items) {
+    if (t) {
+      cur = end = 0;
+      tv = request();
+    } else {
+      cur = wave_index() - (int64_t)gridDim.x * WPB;
+      end = 0;
+      tv = 0;
+    }
+  }
+  __device__ __forceinline__ unsigned request() {
+    unsigned v = 0;
+    if ((threadIdx.x & 63) == 0) v = atomicAdd(t, 1u);
+    return v;
+  }
+  // the next item of this wave, or false when the work is exhausted (every wave gets there: tickets only grow)
+  __device__ __forceinline__ bool next(int64_t& item) {
+    if (!t) {
+      cur += (int64_t)gridDim.x * WPB;
+      item = cur;
+      return cur < total;
+    }
+    if (cur == end) {
+      cur = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tv) * TN;
+      if (cur >= total) return false;
+      end = cur + TN < total ? cur + TN : total;
+      tv = request();
+    }
+    item = cur++;
+    return true;
+  }
+};
+constexpr size_t TICKET_STRIDE = 16;            // unsigned per counter: one 64-byte line each
+constexpr size_t TICKET_BYTES = 16 * TICKET_STRIDE * sizeof(unsigned);
+
 #ifndef HOTK_GRID_CAP
 #define HOTK_GRID_CAP (1 << 20)
 #endif
@@ -531,12 +588,14 @@ __device__ __forceinline__ void graphsum_rows(const Lane& L, const A& a, float* 
 }
 
 template <class ST>
-__global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+__global__ __launch_bounds__(TPB) void k_graphsum_fwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk, unsigned* __restrict__ ticket) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  WorkIter<1> it(ticket, nwork);
+  int64_t w;
+  while (it.next(w)) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];   // rows below are the diagonal (layout invariant)
@@ -766,14 +825,16 @@ __global__ __launch_bounds__(TPB) void k_node_dd(A a) {
 // GT: also the per-graph terms and the zero fill (false: k_graph_apply_fwd_t does them)
 // LOADKV: the node's sums come from a.kvn (split-phase mode) instead of being accumulated here
 template <class ST, int P, bool GT = true, bool LOADKV = false>
-__global__ __launch_bounds__(TPB) void k_seg_fwd(A a) {
+__global__ __launch_bounds__(TPB) void k_seg_fwd(A a, unsigned* __restrict__ ticket) {
   const SV<ST> S(a);
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   float* kvbuf = kvbuf_all[threadIdx.x >> 6];
-  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+  WorkIter<HOTK_TICKET_NODES> it(ticket, a.Nn);
+  int64_t n;
+  while (it.next(n)) {
     if (!a.nkind[n]) continue;
     float rot0[NM], rot1[NM];
     {
@@ -920,12 +981,14 @@ __device__ __forceinline__ void graph_apply_bwd_rows(const LaneB& L, const A& a,
 }
 
 template <class ST>
-__global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk) {
+__global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk, unsigned* __restrict__ ticket) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  WorkIter<1> it(ticket, nwork);
+  int64_t w;
+  while (it.next(w)) {
     int64_t b, r0, r1;
     chunk_rows(a, w, cpg, rows_per_chunk, &b, &r0, &r1);
     const int64_t nodes_end = b * a.Emax + a.n_nodes[b];
@@ -1000,14 +1063,16 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
 // wave per chunk of 16 consecutive rows of one kind of one graph; one instantiation per kind, so that only that kind's
 // two dKVg slots (F layout + rotated) are live
 template <class ST, bool DIAG, int ROWS = GB_ROWS>
-__global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
+__global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a, unsigned* __restrict__ ticket) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   const int64_t span = DIAG ? a.Nmax : a.Emax;
   const int64_t cpg = (span + ROWS - 1) / ROWS;
   const int64_t nwork = a.B * cpg;
-  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  WorkIter<1> it(ticket, nwork);
+  int64_t w;
+  while (it.next(w)) {
     const int64_t b = w / cpg, k = w - b * cpg;
     const int64_t nn = a.n_nodes[b];
     const int64_t lo = b * a.Emax + (DIAG ? 0 : nn), hi = b * a.Emax + (DIAG ? nn : (int64_t)a.n_entries[b]);
@@ -1027,7 +1092,7 @@ __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a) {
 // a.kvn, d(sums) go to a.dkvn for the caller to all-reduce), MODE 2 = key / value side only (d(sums) from a.dkvn),
 // MODE 3 = key / value side of part 0 (d(sums) rebuilt from the all-reduced [d num | d den] of the node queries)
 template <class ST, int P, int MODE = 0>
-__global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
+__global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a, unsigned* __restrict__ ticket) {
   const SV<ST> S(a);
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
@@ -1035,7 +1100,9 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a) {
   float* stage = stage_all[threadIdx.x >> 6];
   float* kvbuf = kvbuf_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
-  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+  WorkIter<HOTK_TICKET_NODES> it(ticket, a.Nn);
+  int64_t n;
+  while (it.next(n)) {
     if (!a.nkind[n]) continue;
     float dkv[2][NC + 1];
     if constexpr (MODE == 3) {
@@ -1381,14 +1448,16 @@ __device__ __forceinline__ void tile_rows(const LaneT& L, const A& a, int32_t t0
 }
 
 template <class ST, int P>
-__global__ __launch_bounds__(TPB, 4) void k_segt_fwd(A a) {
+__global__ __launch_bounds__(TPB, 4) void k_segt_fwd(A a, unsigned* __restrict__ ticket) {
   const SV<ST> S(a);
   __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
   float* tile = tile_all[threadIdx.x >> 6];
   const LaneT L = make_lane_t(a.proj);
   constexpr int QC = P == 1 ? 0 : 2 * SLOT;                                             // raw query slots 0, 1 / 2, 3
   constexpr int OA = P == 1 ? 2 * SLOT : 3 * SLOT, OB = P == 1 ? 4 * SLOT : 5 * SLOT;   // terms 3, 5 / 4, 6
-  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+  WorkIter<HOTK_TICKET_NODES> it(ticket, a.Nn);
+  int64_t n;
+  while (it.next(n)) {
     // P == 1: entries of column n, terms 3, 5;  P == 2: entries of row n, terms 4, 6 (sums of their ROW node)
     const int32_t c0 = P == 1 ? a.col_ptr[n] : a.row_ptr[n];
     int32_t c1 = P == 1 ? a.col_ptr[n + 1] : a.row_ptr[n + 1];
@@ -1436,14 +1505,16 @@ constexpr int GA_TILES = 8;   // 16-row tiles per wave
 #define HOTK_GA_WAVES 4
 #endif
 template <class ST>
-__global__ __launch_bounds__(TPB, HOTK_GA_WAVES) void k_graph_apply_fwd_t(A a) {
+__global__ __launch_bounds__(TPB, HOTK_GA_WAVES) void k_graph_apply_fwd_t(A a, unsigned* __restrict__ ticket) {
   const SV<ST> S(a);
   __shared__ __align__(16) float tile_all[WPB][TILE_FLOATS];
   float* tile = tile_all[threadIdx.x >> 6];
   const LaneT L = make_lane_t(a.proj);
   const int64_t nd = (a.Nmax + 16 * GA_TILES - 1) / (16 * GA_TILES), no = (a.Emax + 16 * GA_TILES - 1) / (16 * GA_TILES);
   const int64_t nwork = a.B * (nd + no);
-  for (int64_t w = wave_index(); w < nwork; w += (int64_t)gridDim.x * WPB) {
+  WorkIter<1> it(ticket, nwork);
+  int64_t w;
+  while (it.next(w)) {
     const int64_t b = w / (nd + no), k = w - b * (nd + no);
     const bool diag = k < nd;
     const int32_t nn = a.n_nodes[b], ne = a.n_entries[b];
@@ -1543,16 +1614,22 @@ void chunking(int64_t B, int64_t Emax, int* cpg, int* rows) {
   *rows = (int)((Emax + c - 1) / c);
 }
 
+// grid of a kernel that draws tickets (tk != nullptr: persistent workgroups) or walks with a static stride
+inline dim3 work_grid(int64_t items, const unsigned* tk) {
+  return dim3(hotk_grid(items, WPB, tk ? (int64_t)HOTK_DYN_GRID : GRID_CAP));
+}
+inline unsigned* tk_slot(unsigned* tickets, int i) { return tickets ? tickets + i * TICKET_STRIDE : nullptr; }
+
 template <class ST>
-void launch_graphsum_bwd(hipStream_t st, const A* a) {
+void launch_graphsum_bwd(hipStream_t st, const A* a, unsigned* tickets) {
   if (a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS) < 2048) {
     constexpr int RW = GB_ROWS_SMALL;
-    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), work_grid(a->B * ((a->Nmax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 4));
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), work_grid(a->B * ((a->Emax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 5));
   } else {
     constexpr int RW = GB_ROWS;
-    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), dim3(hotk_grid(a->B * ((a->Nmax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), dim3(hotk_grid(a->B * ((a->Emax + RW - 1) / RW), WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), work_grid(a->B * ((a->Nmax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 4));
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), work_grid(a->B * ((a->Emax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 5));
   }
 }
 
@@ -1569,7 +1646,8 @@ extern "C" int hotk_attn22_workspace_bytes(int64_t B, int64_t Emax, size_t* byte
   HOTK_CHECK_ARG(bytes && B >= 0 && Emax >= 0);
   int cpg, rows;
   chunking(B, Emax, &cpg, &rows);
-  *bytes = (size_t)B * cpg * 4 * (NC + 1) * 64 * sizeof(float);
+  // per-chunk partial graph sums, then the work tickets of the persistent kernels (one 64-byte line per kernel)
+  *bytes = (size_t)B * cpg * 4 * (NC + 1) * 64 * sizeof(float) + TICKET_BYTES;
   return HOTK_OK;
 }
 
@@ -1577,29 +1655,34 @@ namespace {
 // forward launches; `part` holds the per-chunk partial graph sums (hotk_attn22_workspace_bytes): every chunk of it is
 // written by k_graphsum_fwd before k_graph_reduce reads it, so it needs no clearing
 template <class ST>
-int attn22_forward_launch_t(const A* a, float* part, hipStream_t st) {
+int attn22_forward_launch_t(const A* a, float* part, unsigned* tickets, hipStream_t st) {
   int cpg, rows;
   chunking(a->B, a->Emax, &cpg, &rows);
-  unsigned g1 = hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP);
-  hipLaunchKernelGGL(k_graphsum_fwd<ST>, dim3(g1), dim3(TPB), 0, st, *a, part, cpg, rows);
+  if (tickets && hipMemsetAsync(tickets, 0, TICKET_BYTES, st) != hipSuccess) return HOTK_ELAUNCH;
+  hipLaunchKernelGGL(k_graphsum_fwd<ST>, work_grid((int64_t)a->B * cpg, nullptr), dim3(TPB), 0, st, *a, part, cpg, rows, (unsigned*)nullptr);
   launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
-  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
+  const dim3 gseg = work_grid(a->Nn, tickets);
   if (core_valu()) {
-    hipLaunchKernelGGL((k_seg_fwd<ST, 1, true>), gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_seg_fwd<ST, 2, true>), gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_seg_fwd<ST, 0, true>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL((k_seg_fwd<ST, 1, true>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+    hipLaunchKernelGGL((k_seg_fwd<ST, 2, true>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
+    hipLaunchKernelGGL((k_seg_fwd<ST, 0, true>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 3));
   } else {
     const int64_t per = 16 * GA_TILES;
     const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
-    hipLaunchKernelGGL(k_graph_apply_fwd_t<ST>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_segt_fwd<ST, 1>), gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_segt_fwd<ST, 2>), gseg, dim3(TPB), 0, st, *a);
-    hipLaunchKernelGGL((k_seg_fwd<ST, 0, false>), gseg, dim3(TPB), 0, st, *a);
+    hipLaunchKernelGGL(k_graph_apply_fwd_t<ST>, work_grid(nga, nullptr), dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+    hipLaunchKernelGGL((k_segt_fwd<ST, 1>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+    hipLaunchKernelGGL((k_segt_fwd<ST, 2>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
+    hipLaunchKernelGGL((k_seg_fwd<ST, 0, false>), work_grid(a->Nn, nullptr), dim3(TPB), 0, st, *a, (unsigned*)nullptr);
   }
   return hotk_launch_status();
 }
-int attn22_forward_launch(const A* a, float* part, hipStream_t st) {
-  return a->storage == HOTK_STORAGE_BF16 ? attn22_forward_launch_t<bf16>(a, part, st) : attn22_forward_launch_t<float>(a, part, st);
+// workspace = [partial graph sums | tickets]: the counters sit in the last TICKET_BYTES of hotk_attn22_workspace_bytes
+unsigned* ws_tickets(void* workspace, size_t need) {
+  return HOTK_DYN ? reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - TICKET_BYTES) : nullptr;
+}
+int attn22_forward_launch(const A* a, float* part, unsigned* tickets, hipStream_t st) {
+  return a->storage == HOTK_STORAGE_BF16 ? attn22_forward_launch_t<bf16>(a, part, tickets, st)
+                                        : attn22_forward_launch_t<float>(a, part, tickets, st);
 }
 }  // namespace
 
@@ -1611,7 +1694,7 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-  return attn22_forward_launch(a, (float*)workspace, (hipStream_t)stream);
+  return attn22_forward_launch(a, (float*)workspace, ws_tickets(workspace, need), (hipStream_t)stream);
 }
 
 // ---- the forward core for callers that cannot allocate (include/hotk.h: hotk_attn22_forward_static) ----------
@@ -1651,19 +1734,20 @@ extern "C" int hotk_attn22_forward_static(const hotk_attn22_args* a, void* strea
   float* part = nullptr;
   rc = static_scratch(&part);
   if (rc) return rc;
-  return attn22_forward_launch(a, part, (hipStream_t)stream);
+  return attn22_forward_launch(a, part, ws_tickets(part, need), (hipStream_t)stream);
 }
 
 namespace {
 template <class ST>
-int attn22_backward_launch_t(const A* a, float* part, int cpg, int rows, hipStream_t st) {
-  hipLaunchKernelGGL(k_graph_apply_bwd<ST>, dim3(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, part, cpg, rows);
+int attn22_backward_launch_t(const A* a, float* part, unsigned* tickets, int cpg, int rows, hipStream_t st) {
+  if (tickets && hipMemsetAsync(tickets, 0, TICKET_BYTES, st) != hipSuccess) return HOTK_ELAUNCH;
+  hipLaunchKernelGGL(k_graph_apply_bwd<ST>, work_grid((int64_t)a->B * cpg, nullptr), dim3(TPB), 0, st, *a, part, cpg, rows, (unsigned*)nullptr);
   launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
-  launch_graphsum_bwd<ST>(st, a);
-  const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
-  hipLaunchKernelGGL((k_seg_bwd<ST, 1>), gseg, dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL((k_seg_bwd<ST, 2>), gseg, dim3(TPB), 0, st, *a);
-  hipLaunchKernelGGL((k_seg_bwd<ST, 0>), gseg, dim3(TPB), 0, st, *a);
+  launch_graphsum_bwd<ST>(st, a, nullptr);      // (the streaming kernels gain nothing from tickets: measured)
+  const dim3 gseg = work_grid(a->Nn, tickets);
+  hipLaunchKernelGGL((k_seg_bwd<ST, 1>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+  hipLaunchKernelGGL((k_seg_bwd<ST, 2>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
+  hipLaunchKernelGGL((k_seg_bwd<ST, 0>), gseg, dim3(TPB), 0, st, *a, tk_slot(tickets, 3));
   return hotk_launch_status();
 }
 }  // namespace
@@ -1684,8 +1768,9 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
   float* part = (float*)workspace;
-  return a->storage == HOTK_STORAGE_BF16 ? attn22_backward_launch_t<bf16>(a, part, cpg, rows, st)
-                                        : attn22_backward_launch_t<float>(a, part, cpg, rows, st);
+  unsigned* tickets = ws_tickets(workspace, need);
+  return a->storage == HOTK_STORAGE_BF16 ? attn22_backward_launch_t<bf16>(a, part, tickets, cpg, rows, st)
+                                        : attn22_backward_launch_t<float>(a, part, tickets, cpg, rows, st);
 }
 
 // The core in phases for one graph sharded by entries (include/hotk.h): the caller all-reduces kvg / kvn after the
@@ -1710,7 +1795,7 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   switch (phase) {
     case HOTK_ATTN22_FWD_GRAPHSUM:
       if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-      hipLaunchKernelGGL(k_graphsum_fwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
+      hipLaunchKernelGGL(k_graphsum_fwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows, (unsigned*)nullptr);
       launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
       break;
     case HOTK_ATTN22_FWD_NODESUM:
@@ -1722,9 +1807,9 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       HOTK_CHECK_ARG(a->att && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
       const int64_t per = 16 * GA_TILES;
       const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
-      hipLaunchKernelGGL(k_graph_apply_fwd_t<float>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gseg, dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL(k_graph_apply_fwd_t<float>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+      hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+      hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
       hipLaunchKernelGGL(k_node_apply_nd, gseg, dim3(TPB), 0, st, *a);
       break;
     }
@@ -1737,16 +1822,16 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       HOTK_CHECK_ARG(!a->dout || a->ld_dout >= a->D);
       if (phase == HOTK_ATTN22_BWD_QUERY) {
         if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-        hipLaunchKernelGGL(k_graph_apply_bwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows);
+        hipLaunchKernelGGL(k_graph_apply_bwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows, (unsigned*)nullptr);
         launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
-        hipLaunchKernelGGL((k_seg_bwd<float, 1, 1>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<float, 2, 1>), gseg, dim3(TPB), 0, st, *a);
+        hipLaunchKernelGGL((k_seg_bwd<float, 1, 1>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+        hipLaunchKernelGGL((k_seg_bwd<float, 2, 1>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
         hipLaunchKernelGGL(k_node_dd, gseg, dim3(TPB), 0, st, *a);
       } else {
-        launch_graphsum_bwd<float>(st, a);
-        hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gseg, dim3(TPB), 0, st, *a);
-        hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gseg, dim3(TPB), 0, st, *a);
+        launch_graphsum_bwd<float>(st, a, nullptr);
+        hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+        hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+        hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
       }
       break;
   }
