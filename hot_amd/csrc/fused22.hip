@@ -490,7 +490,11 @@ struct WorkIter {
   unsigned* t;
   int64_t total, cur, end;
   unsigned tv;
+  int tn;      // items per ticket: at most TN, fewer when that would leave a wave under ~16 tickets (few long segments:
+               // one graph of 125 k nodes with 50 entries each ran 5 % slower with 8-node tickets than with a static stride)
   __device__ __forceinline__ WorkIter(unsigned* __restrict__ ticket, int64_t n_items) : t(ticket), total(n_items) {
+    const int64_t per = n_items / ((int64_t)gridDim.x * WPB * 16);
+    tn = per < 1 ? 1 : (per > TN ? TN : (int)per);
     if (t) {
       cur = end = 0;
       tv = request();
@@ -513,9 +517,9 @@ struct WorkIter {
       return cur < total;
     }
     if (cur == end) {
-      cur = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tv) * TN;
+      cur = (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tv) * tn;
       if (cur >= total) return false;
-      end = cur + TN < total ? cur + TN : total;
+      end = cur + tn < total ? cur + tn : total;
       tv = request();
     }
     item = cur++;
@@ -753,13 +757,15 @@ __device__ __forceinline__ float* dkvn_slot(const A& a, int64_t n, int s) {
 // phi(q) . KV is linear in KV, so a rank applies its PARTIAL sums and only [numerator | normaliser] (nd0: 64 floats per
 // slot in the C layout instead of 576) is all-reduced; the partial sums stay local for the backward pass.
 template <int P>
-__global__ __launch_bounds__(TPB) void k_seg_kvsum(A a) {
+__global__ __launch_bounds__(TPB) void k_seg_kvsum(A a, unsigned* __restrict__ ticket) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
   const Lane L = make_lane(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
   float* kvbuf = kvbuf_all[threadIdx.x >> 6];
-  for (int64_t n = wave_index(); n < a.Nn; n += (int64_t)gridDim.x * WPB) {
+  WorkIter<HOTK_TICKET_NODES> it(ticket, a.Nn);
+  int64_t n;
+  while (it.next(n)) {
     if (!a.nkind[n]) continue;
     float kv[2][NC + 1];
     seg_accumulate<float, P, true>(L, a, stage, (int32_t)n, kv);
@@ -1677,8 +1683,12 @@ int attn22_forward_launch_t(const A* a, float* part, unsigned* tickets, hipStrea
   return hotk_launch_status();
 }
 // workspace = [partial graph sums | tickets]: the counters sit in the last TICKET_BYTES of hotk_attn22_workspace_bytes
-unsigned* ws_tickets(void* workspace, size_t need) {
-  return HOTK_DYN ? reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - TICKET_BYTES) : nullptr;
+// Tickets pay where the nodes are many and their segments short (C1 / C2: ~10 entries per node, a node-wave lives ~20 us
+// and the dispatcher cannot keep the slots full); on ONE graph of 125 k nodes with 50 entries each (the C5 shard) the
+// static stride with a workgroup per node is faster (phases 17.6 ms against 19.2-22.6 ms with tickets of 8 / 1 nodes).
+unsigned* ws_tickets(const A* a, void* workspace, size_t need) {
+  const bool short_segments = a->R < 24 * a->Nn;
+  return (HOTK_DYN && short_segments) ? reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - TICKET_BYTES) : nullptr;
 }
 int attn22_forward_launch(const A* a, float* part, unsigned* tickets, hipStream_t st) {
   return a->storage == HOTK_STORAGE_BF16 ? attn22_forward_launch_t<bf16>(a, part, tickets, st)
@@ -1694,7 +1704,7 @@ extern "C" int hotk_attn22_forward(const hotk_attn22_args* a, void* workspace, s
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
-  return attn22_forward_launch(a, (float*)workspace, ws_tickets(workspace, need), (hipStream_t)stream);
+  return attn22_forward_launch(a, (float*)workspace, ws_tickets(a, workspace, need), (hipStream_t)stream);
 }
 
 // ---- the forward core for callers that cannot allocate (include/hotk.h: hotk_attn22_forward_static) ----------
@@ -1734,7 +1744,7 @@ extern "C" int hotk_attn22_forward_static(const hotk_attn22_args* a, void* strea
   float* part = nullptr;
   rc = static_scratch(&part);
   if (rc) return rc;
-  return attn22_forward_launch(a, part, ws_tickets(part, need), (hipStream_t)stream);
+  return attn22_forward_launch(a, part, ws_tickets(a, part, need), (hipStream_t)stream);
 }
 
 namespace {
@@ -1768,7 +1778,7 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
   float* part = (float*)workspace;
-  unsigned* tickets = ws_tickets(workspace, need);
+  unsigned* tickets = ws_tickets(a, workspace, need);
   return a->storage == HOTK_STORAGE_BF16 ? attn22_backward_launch_t<bf16>(a, part, tickets, cpg, rows, st)
                                         : attn22_backward_launch_t<float>(a, part, tickets, cpg, rows, st);
 }
@@ -1790,7 +1800,12 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
   size_t need;
   hotk_attn22_workspace_bytes(a->B, a->Emax, &need);
   float* part = (float*)workspace;
+  // the node-segment kernels draw tickets when the caller's workspace has room for them (it does when it was sized by
+  // hotk_attn22_workspace_bytes); the light per-node kernels and the streaming kernels keep the static stride
+  unsigned* tickets = (workspace && ws_bytes >= need) ? ws_tickets(a, workspace, need) : nullptr;
+  if (tickets && hipMemsetAsync(tickets, 0, TICKET_BYTES, st) != hipSuccess) return HOTK_ELAUNCH;
   const dim3 gseg(hotk_grid(a->Nn, WPB, GRID_CAP));
+  const dim3 gdyn = work_grid(a->Nn, tickets);
   const dim3 gchunk(hotk_grid((int64_t)a->B * cpg, WPB, GRID_CAP));
   switch (phase) {
     case HOTK_ATTN22_FWD_GRAPHSUM:
@@ -1799,17 +1814,17 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       launch_graph_reduce(st, part, a->kvg, a->B, cpg, 0);
       break;
     case HOTK_ATTN22_FWD_NODESUM:
-      hipLaunchKernelGGL(k_seg_kvsum<0>, gseg, dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL(k_seg_kvsum<1>, gseg, dim3(TPB), 0, st, *a);
-      hipLaunchKernelGGL(k_seg_kvsum<2>, gseg, dim3(TPB), 0, st, *a);
+      hipLaunchKernelGGL(k_seg_kvsum<0>, gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 0));
+      hipLaunchKernelGGL(k_seg_kvsum<1>, gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+      hipLaunchKernelGGL(k_seg_kvsum<2>, gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
       break;
     case HOTK_ATTN22_FWD_APPLY: {
       HOTK_CHECK_ARG(a->att && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
       const int64_t per = 16 * GA_TILES;
       const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
       hipLaunchKernelGGL(k_graph_apply_fwd_t<float>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, (unsigned*)nullptr);
-      hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
-      hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+      hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+      hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
       hipLaunchKernelGGL(k_node_apply_nd, gseg, dim3(TPB), 0, st, *a);
       break;
     }
@@ -1824,14 +1839,14 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
         if (!workspace || ws_bytes < need) return HOTK_EWORKSPACE;
         hipLaunchKernelGGL(k_graph_apply_bwd<float>, gchunk, dim3(TPB), 0, st, *a, part, cpg, rows, (unsigned*)nullptr);
         launch_graph_reduce(st, part, a->dkvg, a->B, cpg, 1);
-        hipLaunchKernelGGL((k_seg_bwd<float, 1, 1>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
-        hipLaunchKernelGGL((k_seg_bwd<float, 2, 1>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+        hipLaunchKernelGGL((k_seg_bwd<float, 1, 1>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+        hipLaunchKernelGGL((k_seg_bwd<float, 2, 1>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
         hipLaunchKernelGGL(k_node_dd, gseg, dim3(TPB), 0, st, *a);
       } else {
         launch_graphsum_bwd<float>(st, a, nullptr);
-        hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
-        hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
-        hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gseg, dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+        hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+        hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
+        hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 0));
       }
       break;
   }
