@@ -285,7 +285,9 @@ int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t l
  * backward: datt [R,10*32] -> dh1 [Nn,12*32] (key slots 4..9 are NOT written here: they are the row-segment sum of
  * ck [R,6*32], hotk_seg_sum_rows over the row CSR), dh2 [R, 8*32 (+D)] (skip-path columns = dout when given,
  * zero otherwise), dv [R,10*32]; padding rows of dh1/dh2/dv are left untouched.  dkvg [B,4,25,64] scratch.
- * workspace: hotk_attn22_workspace_bytes(B, Emax) (per-chunk partial graph sums).
+ * workspace: hotk_attn22_workspace_bytes(B, Emax): per-chunk partial graph sums, then 1 KB of work tickets -- on batches
+ * of many short segments the node kernels run as persistent waves that draw runs of consecutive nodes from counters
+ * there (cleared by a memset node at the start of every call; calls sharing one workspace must not overlap).
  * ---------------------------------------------------------------------------------------------- */
 #define HOTK_STORAGE_F32 0
 #define HOTK_STORAGE_BF16 1
