@@ -163,8 +163,15 @@ struct Lane {
   int lane, h, x;
   float ps[DH];  // F layout: P[x][:] * d^-1/4
 };
+#ifndef HOTK_LDS_DOT
+#define HOTK_LDS_DOT 1
+#endif
 struct LaneB : Lane {
-  float pr[NR8];  // rotated projection: P[(x - k) & 15][x & 7] * d^-1/4, k < 8 (rot_dot8; backward kernels only)
+  // projection table of the contraction d(raw)[x & 7] = sum_mm dpre[mm] P[mm][x & 7] (backward kernels only):
+  // HOTK_LDS_DOT: the lane's half of the features, P[(x & 8) + k][x & 7]; else rotated, P[(x - k) & 15][x & 7], k < 8
+  float pr[NR8];
+  float* cb;      // LDS form: 64 floats of wave-private LDS through which a head's 16 values meet
+  bool lds;       // which form this kernel's contractions take (a compile-time constant after inlining)
 };
 
 constexpr float PSCALE = 0.59460355750136051f;  // 8^-1/4
@@ -181,12 +188,35 @@ __device__ __forceinline__ Lane make_lane(const float* __restrict__ proj) {
   init_lane(L, proj);
   return L;
 }
-__device__ __forceinline__ LaneB make_lane_b(const float* __restrict__ proj) {
+__device__ __forceinline__ LaneB make_lane_b(const float* __restrict__ proj, float* cb, bool lds) {
   LaneB L;
   init_lane(L, proj);
+  L.cb = cb;
+  L.lds = lds && HOTK_LDS_DOT;
 #pragma unroll
-  for (int k = 0; k < NR8; ++k) L.pr[k] = proj[ror_src(L.x, k) * DH + (L.x & 7)] * PSCALE;
+  for (int k = 0; k < NR8; ++k)
+    L.pr[k] = proj[(L.lds ? (L.x & 8) + k : ror_src(L.x, k)) * DH + (L.x & 7)] * PSCALE;
   return L;
+}
+// out[x & 7] = sum over the head's 16 lanes mm of v[mm] * T[mm][x & 7], on every lane of the head.  A DPP operand costs a
+// second issue slot: the rotation form is 1 + 7 DPP multiply-adds + 2 adds = 18 slots.  In the LDS form the head's values
+// meet in LDS instead: one ds_write_b32, two ds_read_b128 (the lane's half of the features, broadcast reads), 8 plain
+// multiply-adds and the cross-half add = 11 vector slots + 3 LDS instructions (tab[k] = T[(x & 8) + k][x & 7]).  Measured
+// with the slots full: the streaming per-graph kernels gain (k_graphsum_bwd 2.9 -> 2.7 ms, k_graph_apply_bwd 2.3 -> 2.1),
+// the node-segment kernels lose a little (k_seg_bwd 5.65 -> 5.8 ms: their LDS staging is already busy) and keep DPP.
+__device__ __forceinline__ float contract8(const LaneB& L, float v, const float (&tab)[NR8]) {
+  if (!L.lds) return rot_dot8(v, tab);
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  L.cb[L.lane] = v;
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const float* p = L.cb + (L.lane & ~7);
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  float s = a.x * tab[0];
+  s = fmaf(a.y, tab[1], s); s = fmaf(a.z, tab[2], s); s = fmaf(a.w, tab[3], s);
+  s = fmaf(b.x, tab[4], s); s = fmaf(b.y, tab[5], s); s = fmaf(b.z, tab[6], s); s = fmaf(b.w, tab[7], s);
+  return s + ror<8>(s);
 }
 
 __device__ __forceinline__ float phi_of(float pre) { return fmaxf(pre, 0.f) + PHI_EPS; }
@@ -200,7 +230,7 @@ __device__ __forceinline__ float pre_x(const Lane& L, const float (&x)[DH]) {
 }
 
 // d(raw q or k)[x & 7] = sum_mm dpre[mm] P[mm][x & 7] (all 16 lanes of the head hold it)
-__device__ __forceinline__ float proj_back(const LaneB& L, float dpre) { return rot_dot8(dpre, L.pr); }
+__device__ __forceinline__ float proj_back(const LaneB& L, float dpre) { return contract8(L, dpre, L.pr); }
 
 // the 8-float slice of head h of a 32-float slot staged in the wave's LDS row
 __device__ __forceinline__ void slice8(const Lane& L, const float* lds_slot, float (&o)[8]) {
@@ -316,7 +346,7 @@ __device__ __forceinline__ void kv_bwd(const LaneB& L, const float (&k)[DH], con
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
-  const float dvv = rot_dot8(phi, drot);
+  const float dvv = contract8(L, phi, drot);
   if (dv) stS(dv + L.h * NC + (L.x & 7), dvv);
   const float dpre = pre > 0.f ? dphi : 0.f;
   const float d = proj_back(L, dpre);
@@ -330,7 +360,7 @@ __device__ __forceinline__ void kv_bwd_phi(const LaneB& L, float phi, const floa
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
-  const float dvv = rot_dot8(phi, drot);
+  const float dvv = contract8(L, phi, drot);
   if (dv) stS(dv + L.h * NC + (L.x & 7), dvv);
   const float dpre = phi > PHI_EPS ? dphi : 0.f;
   const float d = proj_back(L, dpre);
@@ -345,7 +375,7 @@ __device__ __forceinline__ void kv_bwd_phi_w(const LaneB& L, float phi, float w,
   float dphi = dkv[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) dphi = fmaf(dkv[c], val[c], dphi);
-  const float dvv = rot_dot8(phi * w, drot);
+  const float dvv = contract8(L, phi * w, drot);
   if (dv) stS(dv + L.h * NC + (L.x & 7), dvv);
   const float dpre = phi > PHI_EPS ? dphi * w : 0.f;
   const float d = proj_back(L, dpre);
@@ -443,6 +473,17 @@ template <int NK>
 __device__ __forceinline__ void kvg_load_rot(const Lane& L, const float* __restrict__ slot, float (&rot)[NK]) {
 #pragma unroll
   for (int k = 0; k < NK; ++k) rot[k] = slot[(NC + 1 + k) * 64 + L.lane];
+}
+// the 8-entry table of contract8 for a per-graph sum in memory: the lane's half of the features from the feature-major
+// channels (HOTK_LDS_DOT), else the rotated copies
+__device__ __forceinline__ void kvg_load_tab8(const LaneB& L, const float* __restrict__ slot, float (&tab)[NR8]) {
+  if (L.lds) {
+    const float* p = slot + (L.x & 7) * 64 + L.h * 16 + (L.x & 8);
+#pragma unroll
+    for (int k = 0; k < NR8; ++k) tab[k] = p[k];
+  } else {
+    kvg_load_rot<NR8>(L, slot, tab);
+  }
 }
 // partial sums of one chunk: [4][9][64]
 __device__ __forceinline__ void part_store(const Lane& L, float* __restrict__ base, const float (&kv)[NC + 1]) {
@@ -989,8 +1030,8 @@ __device__ __forceinline__ void graph_apply_bwd_rows(const LaneB& L, const A& a,
 template <class ST>
 __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict__ dst, int cpg, int rows_per_chunk, unsigned* __restrict__ ticket) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
-  const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
+  const LaneB L = make_lane_b(a.proj, stage + 4 * 64, true);
   const int64_t nwork = a.B * cpg;
   WorkIter<1> it(ticket, nwork);
   int64_t w;
@@ -1019,8 +1060,8 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
   float d0[NC + 1], d1[NC + 1], t0[NR8], t1[NR8];
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), d0);
   kvg_load(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), d1);
-  kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), t0);
-  kvg_load_rot(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), t1);
+  kvg_load_tab8(L, kvg_slot(a.dkvg, b, DIAG ? 0 : 1), t0);
+  kvg_load_tab8(L, kvg_slot(a.dkvg, b, DIAG ? 2 : 3), t1);
   auto load = [&](int k, float (&r)[4]) __attribute__((always_inline)) {
     const int64_t row = ra + k;
     const ST* vr = S.v + row * a.ld_v;
@@ -1071,8 +1112,8 @@ __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, fl
 template <class ST, bool DIAG, int ROWS = GB_ROWS>
 __global__ __launch_bounds__(TPB) void k_graphsum_bwd(A a, unsigned* __restrict__ ticket) {
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
-  const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
+  const LaneB L = make_lane_b(a.proj, stage + 4 * 64, true);
   const int64_t span = DIAG ? a.Nmax : a.Emax;
   const int64_t cpg = (span + ROWS - 1) / ROWS;
   const int64_t nwork = a.B * cpg;
@@ -1102,8 +1143,8 @@ __global__ __launch_bounds__(TPB, HOTK_SEGB_WAVES) void k_seg_bwd(A a, unsigned*
   const SV<ST> S(a);
   __shared__ __align__(16) float stage_all[WPB][STAGE_FLOATS];
   __shared__ __align__(16) float kvbuf_all[WPB][KVBUF_FLOATS];
-  const LaneB L = make_lane_b(a.proj);
   float* stage = stage_all[threadIdx.x >> 6];
+  const LaneB L = make_lane_b(a.proj, stage + 4 * 64, false);
   float* kvbuf = kvbuf_all[threadIdx.x >> 6];
   const bool lo = L.lane < 32;
   WorkIter<HOTK_TICKET_NODES> it(ticket, a.Nn);
