@@ -520,6 +520,12 @@ __device__ __forceinline__ int64_t wave_index() {
 #ifndef HOTK_DYN
 #define HOTK_DYN 1
 #endif
+#ifndef HOTK_TICKET_MIN_NODES
+#define HOTK_TICKET_MIN_NODES 300000
+#endif
+#ifndef HOTK_TICKETS_PER_WAVE
+#define HOTK_TICKETS_PER_WAVE 16
+#endif
 #ifndef HOTK_TICKET_NODES
 #define HOTK_TICKET_NODES 8
 #endif
@@ -534,7 +540,7 @@ struct WorkIter {
   int tn;      // items per ticket: at most TN, fewer when that would leave a wave under ~16 tickets (few long segments:
                // one graph of 125 k nodes with 50 entries each ran 5 % slower with 8-node tickets than with a static stride)
   __device__ __forceinline__ WorkIter(unsigned* __restrict__ ticket, int64_t n_items) : t(ticket), total(n_items) {
-    const int64_t per = n_items / ((int64_t)gridDim.x * WPB * 16);
+    const int64_t per = n_items / ((int64_t)gridDim.x * WPB * HOTK_TICKETS_PER_WAVE);
     tn = per < 1 ? 1 : (per > TN ? TN : (int)per);
     if (t) {
       cur = end = 0;
@@ -1727,9 +1733,15 @@ int attn22_forward_launch_t(const A* a, float* part, unsigned* tickets, hipStrea
 // Tickets pay where the nodes are many and their segments short (C1 / C2: ~10 entries per node, a node-wave lives ~20 us
 // and the dispatcher cannot keep the slots full); on ONE graph of 125 k nodes with 50 entries each (the C5 shard) the
 // static stride with a workgroup per node is faster (phases 17.6 ms against 19.2-22.6 ms with tickets of 8 / 1 nodes).
+// And where there are enough nodes for 8-node tickets: one counter serves ~86 atomics per microsecond, which a batch of
+// 82 k small nodes (4 096 molecules) already exceeds with one node per ticket (the C2-shaped step went 167 -> 200 ms).
+// Eight counters per kernel (one per XCD) lift that limit but let the XCDs drift apart, and the shared window of
+// neighbouring nodes is what the tickets are for (k_seg_bwd 5.6 -> 9.0 ms at C1): one counter, large batches only.
 unsigned* ws_tickets(const A* a, void* workspace, size_t need) {
   const bool short_segments = a->R < 24 * a->Nn;
-  return (HOTK_DYN && short_segments) ? reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - TICKET_BYTES) : nullptr;
+  const bool many_nodes = a->Nn >= HOTK_TICKET_MIN_NODES;
+  return (HOTK_DYN && short_segments && many_nodes) ? reinterpret_cast<unsigned*>(static_cast<char*>(workspace) + need - TICKET_BYTES)
+                                                   : nullptr;
 }
 int attn22_forward_launch(const A* a, float* part, unsigned* tickets, hipStream_t st) {
   return a->storage == HOTK_STORAGE_BF16 ? attn22_forward_launch_t<bf16>(a, part, tickets, st)
