@@ -32,8 +32,9 @@ BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEAD
 # HBM traffic of the fused core per valid entry on THIS workload, from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 # passes (FETCH_SIZE x2 as calibrated on a known 1 GiB copy, MI355X_MICROARCH.md HBM section):
 # profiles/r02_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at the benchmarked size (10 M entries; the
-# round-1 pass at 2 M entries gave 4903 / 8584: per-entry figures are size-independent)
-PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 4886, 'hotk_attn22_backward': 8592}
+# round-1 pass at 2 M entries gave 4903 / 8584, the mid-round-2 pass 4886 / 8592; re-collected at the end of round 2: the
+# ticketed kernels hold more waves resident and re-read more of a node's rows past L2 -- they fetch more and run faster)
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 5259, 'hotk_attn22_backward': 10069}
 PMC_TRAFFIC_SOURCE = 'profiles/r02_pmc_traffic_attn22.txt'
 
 
@@ -350,7 +351,7 @@ def main():
                     'avg_launch_ms': tot_ms / max(calls, 1),
                     'note': 'achieved = algorithmic bytes (operands read once + results written once) of the '
                             'dominant C-ABI kernel / its HIP-event time inside the timed region; the kernel is '
-                            'instruction-issue bound (HBM traffic 1.15-1.25x algorithmic at 2-3 TB/s), see DESIGN.md 4'}
+                            'instruction-issue bound (VALU 86 % busy; L2 -> fabric traffic 1.4-1.5x algorithmic), see DESIGN.md 4'}
         line = {
             'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': value, 'unit': 'entries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,
