@@ -230,6 +230,209 @@ __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
   }
 }
 
+// The two query-side contractions (k_row_contract, k_apply_bwd_stats_c) with the key-value column of a lane kept in
+// REGISTERS across the rows of one segment, for c in {8, 16}, m in {16, 44} (m <= 4 c) and 16-byte aligned query
+// rows.  The thread-per-element kernels fetch a row's 2 m key-value floats per lane again for every row (~100 load
+// instructions per wave and row at m = 44, each spread over 4 x 68 B); rows arrive sorted by their segment (or are
+// visited through `order`), so a lane group that walks QC_ROWS consecutive visits reloads its column only where the
+// segment changes (~1 row in 10).  lane = (row slot, head, channel): 64 / (HH c) rows side by side when a row needs
+// fewer than 64 lanes, each slot walking its own run of consecutive visits; (HH c) / 64 waves per run otherwise.
+// What a wave reads per row besides that: the row's queries -- ONE 16-byte load per lane, QC_PF rows ahead, restaged
+// through a wave-private LDS ring so that every lane reads its head's m floats as broadcast ds_read_b128 -- and the
+// head's normaliser column, which sits in LDS beside the ring (it is the same for the c lanes of a head).  Row ids,
+// segments, kinds and gather indices of all QC_ROWS visits are fetched up front, one visit per lane, and parked in LDS:
+// two dependent round trips per QC_ROWS rows instead of three per row.  Same fmaf chains per element as the thread
+// kernels: same bits.
+#ifndef HOTK_QC_WAVE
+#define HOTK_QC_WAVE 1
+#endif
+constexpr int QC_ROWS = 16, QC_PF = 4, QC_WAVES = 4;
+static_assert((QC_PF & (QC_PF - 1)) == 0, "ring slots are picked with a mask");
+template <int C, int MM, bool STATS>
+__global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
+    const float* __restrict__ Q, int64_t ld_q, const int32_t* __restrict__ qidx, const float* __restrict__ KV,
+    const int32_t* __restrict__ sidx, int64_t seg_div, const uint8_t* __restrict__ kind, unsigned keep,
+    const int32_t* __restrict__ oidx, float* __restrict__ out, int64_t ld_out, int normalize,
+    const float* __restrict__ dO, int64_t ld_do, float* __restrict__ XA, int64_t ld_xa, int64_t n, int HH,
+    const int32_t* __restrict__ order) {
+  constexpr int c1 = C + 1, m = MM;       // (m is a template constant: a guard per feature costs more than the arithmetic)
+  // per wave: query ring [QC_PF][256 floats], normaliser columns [256 floats], visit records [8 slots][QC_ROWS] int4
+  __shared__ __align__(16) float ring_all[QC_WAVES][QC_PF][256];
+  __shared__ __align__(16) float kvd_all[QC_WAVES][256];
+  __shared__ int4 meta_all[QC_WAVES][8 * QC_ROWS];
+  const int W = HH * C, F = HH * m;
+  const int gw = W < 64 ? W : 64, side = 64 / gw, slices = (W + 63) >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int slot = lane / gw, wl = lane - slot * gw;
+  const int hl = wl / C, chn = wl & (C - 1);       // head within the wave's slice, channel
+  const int nq4 = (gw / C) * m >> 2;               // 16-byte pieces of a slot's query floats (<= gw since m <= 4 c)
+  float* ring = &ring_all[wave][0][0] + slot * gw * 4;
+  float* kvd = kvd_all[wave] + slot * gw * 4;
+  int4* meta = meta_all[wave] + slot * QC_ROWS;
+  const int64_t span = (int64_t)side * QC_ROWS;
+  const int64_t items = ((n + span - 1) / span) * slices;
+  const int64_t nwave = (int64_t)gridDim.x * QC_WAVES;
+  for (int64_t it = (int64_t)blockIdx.x * QC_WAVES + wave; it < items; it += nwave) {
+    const int64_t ch = it / slices;
+    const int h0 = (int)(it - ch * slices) * (64 / C);     // first head of this wave's slice
+    const int w = h0 * C + wl, hh = h0 + hl;
+    const int64_t pos0 = ch * span + (int64_t)slot * QC_ROWS;
+    // ---- visit records: (row, segment or -1 = zero result, query row, output row or -1 = nothing written)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int i = wl; i < QC_ROWS; i += gw) {
+      const int64_t pos = pos0 + i;
+      int4 t = make_int4(-1, -1, -1, -1);
+      if (pos < n) {
+        const int64_t r = order ? (int64_t)order[pos] : pos;
+        const int64_t qr = qidx ? (int64_t)qidx[r] : r;
+        const int64_t sg = seg_of(sidx, seg_div, r);
+        t.x = (int)r;
+        t.z = (int)qr;
+        t.w = oidx ? oidx[r] : (int)r;
+        if (sg >= 0 && qr >= 0 && (!kind || hotk_keep(keep, kind[r]))) t.y = (int)sg;
+      }
+      meta[i] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    auto wanted = [&](const int4& t) { return t.y >= 0 && (STATS || t.w >= 0); };
+    float4 qp[QC_PF];
+    float gp[QC_PF];
+#pragma unroll
+    for (int k = 0; k < QC_PF; ++k) {
+      qp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      gp[k] = 0.f;
+      const int4 t = meta[k];
+      if (wanted(t)) {
+        if (wl < nq4) qp[k] = *reinterpret_cast<const float4*>(Q + (int64_t)t.z * ld_q + h0 * m + 4 * wl);
+        if (STATS) gp[k] = dO[(int64_t)t.x * ld_do + w];
+      }
+    }
+    float kvn[MM];
+#pragma unroll
+    for (int mm = 0; mm < MM; ++mm) kvn[mm] = 0.f;
+    int s_cur = -1;
+    // every lane runs all QC_ROWS steps: the shuffles below see whole groups.  The loop stays rolled and the prefetched
+    // operands rotate through qp[] (unrolled, the scheduler parks the records and queries of many steps in registers:
+    // 170-190 VGPRs at m = 44)
+#pragma unroll 1
+    for (int i = 0; i < QC_ROWS; ++i) {
+      const int b = i & (QC_PF - 1);
+      const int4 t = meta[i];
+      const bool on = wanted(t);
+      float* qrow = ring + b * 256;
+      if (on && wl < nq4) *reinterpret_cast<float4*>(qrow + 4 * wl) = qp[0];
+      const float gv = gp[0];
+      float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
+      float gn = 0.f;
+      if (i + QC_PF < QC_ROWS) {              // the operands of the row QC_PF steps ahead
+        const int4 u = meta[i + QC_PF];
+        if (wanted(u)) {
+          if (wl < nq4) qn = *reinterpret_cast<const float4*>(Q + (int64_t)u.z * ld_q + h0 * m + 4 * wl);
+          if (STATS) gn = dO[(int64_t)u.x * ld_do + w];
+        }
+      }
+      float num = 0.f, den = 0.f;
+      if (on) {
+        if (t.y != s_cur) {                   // another segment: this lane's key-value column, the heads' normaliser columns
+          const float* kv = KV + ((int64_t)t.y * F + hh * m) * c1;
+#pragma unroll
+          for (int mm = 0; mm < MM; ++mm) kvn[mm] = kv[mm * c1 + chn];
+          const float* kvs = KV + ((int64_t)t.y * F + h0 * m) * c1 + C;
+          for (int f = wl; f < 4 * nq4; f += gw) kvd[f] = kvs[(int64_t)f * c1];
+          s_cur = t.y;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (on) {
+        const float* qh = qrow + hl * m;
+        const float* kd = kvd + hl * m;
+#pragma unroll
+        for (int mm = 0; mm < MM; mm += 4) {
+            const float4 qv = *reinterpret_cast<const float4*>(qh + mm);
+            const float4 dv = *reinterpret_cast<const float4*>(kd + mm);
+            num = fmaf(qv.x, kvn[mm], num);         den = fmaf(qv.x, dv.x, den);
+            num = fmaf(qv.y, kvn[mm + 1], num);     den = fmaf(qv.y, dv.y, den);
+            num = fmaf(qv.z, kvn[mm + 2], num);     den = fmaf(qv.z, dv.z, den);
+            num = fmaf(qv.w, kvn[mm + 3], num);     den = fmaf(qv.w, dv.w, den);
+            // (an opaque use of den: otherwise the two chains are packed into v_pk_fma_f32, whose operand PAIRS put every
+            // kvn[] into a register pair with a per-step copy of the normaliser value beside it -- 2 m registers and a
+            // v_mov per product; a packed multiply-add takes two issue slots anyway)
+            asm volatile("" : "+v"(den));
+            // (without this the scheduler issues all 2 m / 4 LDS reads of the row first: 88 more registers at m = 44)
+            if ((mm & 4) != 0) __builtin_amdgcn_sched_barrier(0);
+          }
+      }
+      if (!STATS) {
+        if (t.w >= 0) {
+          float o = 0.f;
+          if (on) {
+            if (normalize) {
+              if (den == 0.f) den = 1e-5f;
+              o = num / den;
+            } else {
+              o = num;
+            }
+          }
+          out[(int64_t)t.w * ld_out + w] = o;
+        }
+      } else {
+        // X = dO / den, XA = -(dO . O) / den (k_apply_bwd_stats_c): the channel sum meets through xor shuffles
+        float x = 0.f, part = 0.f, inv = 0.f;
+        bool guarded = false;
+        if (on) {
+          guarded = (den == 0.f);
+          if (guarded) den = 1e-5f;
+          inv = 1.f / den;
+          x = gv * inv;
+          part = gv * (num * inv);
+        }
+#pragma unroll
+        for (int o = 1; o < C; o <<= 1) part += __shfl_xor(part, o, 64);
+        if (t.x >= 0) {
+          out[(int64_t)t.x * ld_out + w] = x;
+          if (chn == 0) XA[(int64_t)t.x * ld_xa + hh] = (on && !guarded) ? -part * inv : 0.f;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k + 1 < QC_PF; ++k) {
+        qp[k] = qp[k + 1];
+        gp[k] = gp[k + 1];
+      }
+      qp[QC_PF - 1] = qn;
+      gp[QC_PF - 1] = gn;
+    }
+  }
+}
+
+template <bool STATS>
+bool launch_query_contract_w(hipStream_t st, const float* Q, int64_t ld_q, const int32_t* qidx, const float* KV,
+                             const int32_t* sidx, int64_t seg_div, const uint8_t* kind, unsigned keep,
+                             const int32_t* oidx, float* out, int64_t ld_out, int normalize, const float* dO,
+                             int64_t ld_do, float* XA, int64_t ld_xa, int64_t n, int HH, int m, int c,
+                             const int32_t* order) {
+  const int W = HH * c;
+  // the feature counts of the shipped head widths: m = int(d log d) = 16 (d = 8), 44 (d = 16); kernel.py:60-63
+  if (!HOTK_QC_WAVE || (c != 8 && c != 16) || (m != 16 && m != 44) || m > 4 * c || (ld_q & 3) || !hotk_aligned16(Q)) return false;
+  if (n >= (int64_t)0x7fffffff) return false;      // visit records hold 32-bit row ids
+  if (!(W <= 64 ? 64 % W == 0 : W % 64 == 0)) return false;
+  const int side = W < 64 ? 64 / W : 1, slices = (W + 63) / 64;
+  const int64_t span = (int64_t)side * QC_ROWS, items = ((n + span - 1) / span) * slices;
+  const dim3 grid(hotk_grid(items, QC_WAVES, 256 * 32)), block(64 * QC_WAVES);
+#define HOTK_QC_LAUNCH(CC, MMX)                                                                                        \
+  hipLaunchKernelGGL((k_query_contract_w<CC, MMX, STATS>), grid, block, 0, st, Q, ld_q, qidx, KV, sidx, seg_div, kind, \
+                     keep, oidx, out, ld_out, normalize, dO, ld_do, XA, ld_xa, n, HH, order)
+  if (c == 8) {
+    HOTK_QC_LAUNCH(8, 16);
+  } else {
+    if (m == 16) HOTK_QC_LAUNCH(16, 16); else HOTK_QC_LAUNCH(16, 44);
+  }
+#undef HOTK_QC_LAUNCH
+  return true;
+}
+
 // thread per (row, feature)
 __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
     const float* __restrict__ KV, const int32_t* __restrict__ sidx, int64_t seg_div, const float* __restrict__ X,
@@ -485,6 +688,9 @@ extern "C" int hotk_row_contract(const float* Q, int64_t ld_q, const int32_t* qi
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(Q && KV && out && ld_q >= (int64_t)HH * m && ld_out >= (int64_t)HH * c);
+  if (launch_query_contract_w<false>((hipStream_t)stream, Q, ld_q, qidx, KV, sidx, seg_div, kind, keep, oidx, out, ld_out,
+                                     normalize, nullptr, 0, nullptr, 0, n, HH, m, c, order))
+    return hotk_launch_status();
   hipLaunchKernelGGL(k_row_contract, dim3(hotk_grid(n * HH * c, AT_THREADS, 256 * 32)), dim3(AT_THREADS), 0,
                      (hipStream_t)stream, Q, ld_q, qidx, KV, sidx, seg_div, kind, keep, oidx, out, ld_out, n, HH, m, c,
                      normalize, order);
@@ -500,6 +706,9 @@ extern "C" int hotk_apply_bwd_stats(const float* Q, int64_t ld_q, const float* K
   HOTK_CHECK_ARG(Q && KV && dO && X && XA && ld_q >= (int64_t)HH * m && ld_do >= (int64_t)HH * c &&
                  ld_x >= (int64_t)HH * c && ld_xa >= HH);
   hipStream_t st = (hipStream_t)stream;
+  if (launch_query_contract_w<true>(st, Q, ld_q, nullptr, KV, sidx, seg_div, kind, keep, nullptr, X, ld_x, 1, dO, ld_do, XA,
+                                    ld_xa, n, HH, m, c, order))
+    return hotk_launch_status();
 #define HOTK_ABS_CASE(CC)                                                                                              \
   case CC:                                                                                                             \
     hipLaunchKernelGGL(k_apply_bwd_stats_c<CC>, dim3(hotk_grid(n * HH * CC, AT_THREADS, 256 * 32)), dim3(AT_THREADS),  \

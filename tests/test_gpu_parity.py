@@ -766,7 +766,8 @@ def test_bf16_storage_mode_ragged_and_dropout():
         assert float(y1[~G0.mask].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('HH,m,c', [(4, 16, 8), (4, 44, 16), (2, 10, 16), (8, 16, 8), (3, 5, 4)])
+@pytest.mark.parametrize('HH,m,c', [(4, 16, 8), (4, 44, 16), (2, 10, 16), (8, 16, 8), (3, 5, 4), (8, 32, 16), (2, 8, 8),
+                                    (1, 48, 16)])
 def test_general_attention_kernels_masks_and_indices(HH, m, c):
     """The four general attention entry points (csrc/attn.hip; kernelattncoef.py:19-71,103-175) called on their own with
     everything the layers can hand them -- index maps with -1 rows, segment ids with -1, row-kind masks, ragged feature
