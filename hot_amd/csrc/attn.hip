@@ -5,6 +5,7 @@
 // KV layout: [n_seg][F = HH*m][c+1] floats; channel c is the normaliser (sum of keys) in the forward
 // pass and the normaliser gradient in the backward pass.
 #include "common.h"
+#include <type_traits>
 
 namespace {
 
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(AT_THREADS) void k_apply_bwd_stats_c(
 #define HOTK_QC_WAVE 1
 #endif
 constexpr int QC_ROWS = 16, QC_PF = 4, QC_WAVES = 4;
-static_assert((QC_PF & (QC_PF - 1)) == 0, "ring slots are picked with a mask");
+static_assert(QC_ROWS % QC_PF == 0, "the row loop runs in groups of QC_PF steps");
 template <int C, int MM, bool STATS>
 __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
     const float* __restrict__ Q, int64_t ld_q, const int32_t* __restrict__ qidx, const float* __restrict__ KV,
@@ -313,24 +314,24 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
 #pragma unroll
     for (int mm = 0; mm < MM; ++mm) kvn[mm] = 0.f;
     int s_cur = -1;
-    // every lane runs all QC_ROWS steps: the shuffles below see whole groups.  The loop stays rolled and the prefetched
-    // operands rotate through qp[] (unrolled, the scheduler parks the records and queries of many steps in registers:
-    // 170-190 VGPRs at m = 44)
+    // every lane runs all QC_ROWS steps: the shuffles below see whole groups.  Groups of QC_PF steps: a step's ring slot
+    // and prefetch registers are compile-time indices (rotating them through moves would wait for the load just issued);
+    // the group loop stays rolled (unrolled, the scheduler parks the records of all 16 steps in registers)
 #pragma unroll 1
-    for (int i = 0; i < QC_ROWS; ++i) {
-      const int b = i & (QC_PF - 1);
+    for (int i0 = 0; i0 < QC_ROWS; i0 += QC_PF)
+#pragma unroll
+    for (int b = 0; b < QC_PF; ++b) {
+      const int i = i0 + b;
       const int4 t = meta[i];
       const bool on = wanted(t);
       float* qrow = ring + b * 256;
-      if (on && wl < nq4) *reinterpret_cast<float4*>(qrow + 4 * wl) = qp[0];
-      const float gv = gp[0];
-      float4 qn = make_float4(0.f, 0.f, 0.f, 0.f);
-      float gn = 0.f;
+      if (on && wl < nq4) *reinterpret_cast<float4*>(qrow + 4 * wl) = qp[b];
+      const float gv = gp[b];
       if (i + QC_PF < QC_ROWS) {              // the operands of the row QC_PF steps ahead
         const int4 u = meta[i + QC_PF];
         if (wanted(u)) {
-          if (wl < nq4) qn = *reinterpret_cast<const float4*>(Q + (int64_t)u.z * ld_q + h0 * m + 4 * wl);
-          if (STATS) gn = dO[(int64_t)u.x * ld_do + w];
+          if (wl < nq4) qp[b] = *reinterpret_cast<const float4*>(Q + (int64_t)u.z * ld_q + h0 * m + 4 * wl);
+          if (STATS) gp[b] = dO[(int64_t)u.x * ld_do + w];
         }
       }
       float num = 0.f, den = 0.f;
@@ -396,13 +397,6 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
           if (chn == 0) XA[(int64_t)t.x * ld_xa + hh] = (on && !guarded) ? -part * inv : 0.f;
         }
       }
-#pragma unroll
-      for (int k = 0; k + 1 < QC_PF; ++k) {
-        qp[k] = qp[k + 1];
-        gp[k] = gp[k + 1];
-      }
-      qp[QC_PF - 1] = qn;
-      gp[QC_PF - 1] = gn;
     }
   }
 }
@@ -477,8 +471,23 @@ __global__ __launch_bounds__(AT_THREADS) void k_row_expand(
 #define HOTK_WAVE_C8 1
 #endif
 constexpr int RX_WAVES = 4;
-constexpr int RX_ROWS = 8;   // consecutive rows a wave walks per feature group: rows that share a segment (sorted entry
+constexpr int RX_ROWS = 16;  // consecutive visits a wave walks per feature group: rows that share a segment (sorted entry
                              // lists, graph-keyed sums) reuse the key-value rows already in registers
+constexpr int RX_PF = 4;     // rows whose operands are in flight ahead of the arithmetic
+constexpr int RX_XF = 256 + 64;   // floats per ring stage: the heads' X pieces (<= 64 x 16 B), then one XA value per head
+static_assert(RX_ROWS % RX_PF == 0, "the row loop runs in groups of RX_PF steps");
+// Row ids, segments, kinds and gather indices of the RX_ROWS visits are fetched up front, one visit per lane, and parked
+// in LDS (two dependent round trips per RX_ROWS rows instead of three per row); a row's X / XA pieces are fetched RX_PF
+// rows ahead by the first lanes (ONE 16-byte load per lane instead of c / 4 broadcast loads by every lane) and restaged
+// through a wave-private LDS ring; the next segment's block is requested one row ahead.  Needs m >= 8 (the heads that
+// a 64-feature group touches then fit the ring).
+// Every global load and store of the row loop is UNCONDITIONAL straight-line code -- lanes and rows that have nothing to
+// fetch read a dummy address (the start of KV), lanes past a partial feature group and visits past the end duplicate
+// the last real one (same value to the same address) -- because gfx9 counts loads and stores in one in-order counter and
+// the compiler can only wait for "all but the last k" when it knows k: with a load or store under a branch or an exec
+// mask it waits for everything (vmcnt(0)) before staging a prefetched row, i.e. for the store of the row before and the
+// prefetches just issued, and the ring hides nothing (measured: 1 us per row either way).  Only the block fetch at a
+// segment change stays conditional.
 template <int C>
 __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
     const float* __restrict__ KV, const int32_t* __restrict__ sidx, int64_t seg_div, const float* __restrict__ X,
@@ -487,8 +496,12 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
     const int32_t* __restrict__ order) {
   constexpr int c1 = C + 1;
   __shared__ float img_all[RX_WAVES][64 * c1];
+  __shared__ __align__(16) float ring_all[RX_WAVES][RX_PF][RX_XF];
+  __shared__ int4 meta_all[RX_WAVES][RX_ROWS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* img = img_all[wave];
+  float* ring = &ring_all[wave][0][0];
+  int4* meta = meta_all[wave];
   const int F = HH * m, NG = (F + 63) >> 6;
   const int64_t chunks = (n + RX_ROWS - 1) / RX_ROWS;
   const int64_t items = chunks * NG;
@@ -498,77 +511,112 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
     const int f0 = (int)(w - ch * NG) << 6;
     const int nf = F - f0 < 64 ? F - f0 : 64;
     const int len = nf * c1;
-    const int f = f0 + lane;
-    const int hh = (lane < nf ? f : f0) / m;
-    const int64_t r0 = ch * RX_ROWS, r1 = r0 + RX_ROWS < n ? r0 + RX_ROWS : n;
-    // the segment of row r, or -1 when the row's output is zero (wave-uniform)
-    auto rowid = [&](int64_t pos) -> int64_t { return order ? (int64_t)order[pos] : pos; };
-    auto seg_on = [&](int64_t r) -> int64_t {
+    const int ln = lane < nf ? lane : nf - 1;      // lanes past a partial group shadow its last feature
+    const int f = f0 + ln;
+    const int hA = f0 / m, nh = (f0 + nf - 1) / m - hA + 1;     // heads this feature group touches
+    const int hl = f / m - hA;
+    const int nx4 = nh * (C / 4);
+    const int64_t r0 = ch * RX_ROWS;
+    // ---- visit records: (row, segment or -1 = zero output, X row or -1, -); visits past the end repeat the last one
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < RX_ROWS) {
+      const int64_t pos = r0 + lane < n ? r0 + lane : n - 1;
+      const int64_t r = order ? (int64_t)order[pos] : pos;
       const int64_t sg = seg_of(sidx, seg_div, r);
-      return (sg >= 0 && (!kind || hotk_keep(keep, kind[r]))) ? sg : -1;
+      int4 t = make_int4((int)r, -1, xidx ? xidx[r] : (int)r, 0);
+      if (sg >= 0 && (!kind || hotk_keep(keep, kind[r]))) t.y = (int)sg;
+      meta[lane] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // one row per step, so the records are wave-uniform: scalar registers, scalar branches
+    auto record = [&](int i) {
+      const int4 v = meta[i];
+      return make_int4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y),
+                       __builtin_amdgcn_readfirstlane(v.z), 0);
     };
+    auto x_addr = [&](const int4& t) -> const float* {      // this lane's 16 bytes of the row's X piece, or the dummy
+      return (t.y >= 0 && t.z >= 0 && lane < nx4) ? X + (int64_t)t.z * ld_x + hA * C + 4 * lane : KV;
+    };
+    auto a_addr = [&](const int4& t) -> const float* {
+      return (XA && t.y >= 0 && lane < nh) ? XA + (int64_t)t.x * ld_xa + hA + lane : KV;
+    };
+    // (named registers, not an array: captured by the step lambda an array stays in scratch memory)
+    float4 xp0, xp1, xp2, xp3;
+    float ap0, ap1, ap2, ap3;
+    auto first = [&](float4& xq, float& aq, const int k) __attribute__((always_inline)) {
+      const int4 t = record(k);
+      xq = *reinterpret_cast<const float4*>(x_addr(t));
+      aq = *a_addr(t);
+    };
+    first(xp0, ap0, 0); first(xp1, ap1, 1); first(xp2, ap2, 2); first(xp3, ap3, 3);
     float kv[c1], pre[c1];
 #pragma unroll
     for (int k = 0; k < c1; ++k) kv[k] = pre[k] = 0.f;
-    int64_t r_nxt = rowid(r0);
-    int64_t s_cur = -1, s_nxt = seg_on(r_nxt);
     auto fetch = [&](int64_t sg) {          // the block's 64 (c + 1) floats, coalesced, into registers
       const float* blk = KV + (sg * F + f0) * c1;
 #pragma unroll
-      for (int k = 0; k < c1; ++k) {
+      for (int k = 0; k < c1; ++k) {      // (a partial group re-reads its last float instead of branching per load)
         const int i = lane + 64 * k;
-        if (i < len) pre[k] = blk[i];
+        pre[k] = blk[i < len ? i : len - 1];
       }
     };
-    if (s_nxt >= 0) fetch(s_nxt);
-    for (int64_t pos = r0; pos < r1; ++pos) {
-      const int64_t r = r_nxt;
-      const int64_t sg = s_nxt;
-      if (sg >= 0 && sg != s_cur) {         // transpose through the wave's LDS image: lane <- row lane of the block
+    int s_cur = -1;
+    const int s_pre = __builtin_amdgcn_readfirstlane(meta[0].y);
+    if (s_pre >= 0) fetch(s_pre);
+    // groups of RX_PF steps: a step's ring slot and prefetch registers are compile-time indices (rotating them through
+    // moves would wait for the load just issued)
+    auto step = [&](float4& xq, float& aq, const int b, const int i) __attribute__((always_inline)) {
+      const int4 t = record(i);
+      float* xs = ring + b * RX_XF;
+      *reinterpret_cast<float4*>(xs + 4 * lane) = xq;      // (64 x 16 B: the whole stage; lanes past the piece hold dummies)
+      xs[256 + lane] = (XA && t.y >= 0) ? aq : 1.f;
+      {                                       // the row RX_PF steps ahead (the last group re-reads the chunk's last row)
+        const int4 u = record(i + RX_PF < RX_ROWS ? i + RX_PF : RX_ROWS - 1);
+        xq = *reinterpret_cast<const float4*>(x_addr(u));
+        aq = *a_addr(u);
+      }
+      if (t.y >= 0 && t.y != s_cur) {         // transpose through the wave's LDS image: lane <- row lane of the block
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int k = 0; k < c1; ++k) {
-          const int i = lane + 64 * k;
-          if (i < len) img[i] = pre[k];
-        }
+        for (int k = 0; k < c1; ++k) img[lane + 64 * k] = pre[k];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        if (lane < nf) {
 #pragma unroll
-          for (int k = 0; k < c1; ++k) kv[k] = img[lane * c1 + k];
-        }
-        s_cur = sg;
+        for (int k = 0; k < c1; ++k) kv[k] = img[ln * c1 + k];
+        s_cur = t.y;
       }
-      // this row's operands first, then the next row's key-value block: the block's latency hides behind this row
-      float4 xv[C / 4];
-      float xa = 1.f;
-      const int64_t xr = xidx ? (int64_t)xidx[r] : r;
-      if (sg >= 0 && lane < nf) {
-        if (xr >= 0) {
-          const float* xp = X + xr * ld_x + hh * C;
-#pragma unroll
-          for (int q = 0; q < C / 4; ++q) xv[q] = *reinterpret_cast<const float4*>(xp + 4 * q);
-        }
-        if (XA) xa = XA[r * ld_xa + hh];
+      // the next row's key-value block: its latency hides behind this row
+      if (i + 1 < RX_ROWS) {
+        const int sn = __builtin_amdgcn_readfirstlane(meta[i + 1].y);
+        if (sn >= 0 && sn != s_cur) fetch(sn);
       }
-      if (pos + 1 < r1) {
-        r_nxt = rowid(pos + 1);
-        s_nxt = seg_on(r_nxt);
-        if (s_nxt >= 0 && s_nxt != s_cur) fetch(s_nxt);
-      }
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       float o = 0.f;
-      if (sg >= 0 && lane < nf) {
-        if (xr >= 0) {
+      if (t.y >= 0) {
+        if (t.z >= 0) {
+          const float* xh = xs + hl * C;
 #pragma unroll
           for (int q = 0; q < C / 4; ++q) {
-            o = fmaf(kv[4 * q + 0], xv[q].x, o); o = fmaf(kv[4 * q + 1], xv[q].y, o);
-            o = fmaf(kv[4 * q + 2], xv[q].z, o); o = fmaf(kv[4 * q + 3], xv[q].w, o);
+            const float4 xv = *reinterpret_cast<const float4*>(xh + 4 * q);
+            o = fmaf(kv[4 * q + 0], xv.x, o); o = fmaf(kv[4 * q + 1], xv.y, o);
+            o = fmaf(kv[4 * q + 2], xv.z, o); o = fmaf(kv[4 * q + 3], xv.w, o);
           }
         }
-        o = fmaf(kv[C], xa, o);
+        o = fmaf(kv[C], xs[256 + hl], o);
       }
-      if (lane < nf) out[r * ld_out + f] = o;
+      out[(int64_t)t.x * ld_out + f] = o;
+    };
+    static_assert(RX_PF == 4, "the group below lists its steps");
+#pragma unroll 1
+    for (int i0 = 0; i0 < RX_ROWS; i0 += RX_PF) {
+      step(xp0, ap0, 0, i0);
+      step(xp1, ap1, 1, i0 + 1);
+      step(xp2, ap2, 2, i0 + 2);
+      step(xp3, ap3, 3, i0 + 3);
     }
   }
 }
@@ -732,7 +780,7 @@ extern "C" int hotk_row_expand(const float* KV, const int32_t* sidx, int64_t seg
   HOTK_CHECK_ARG(dims_ok(HH, m, c) && n >= 0 && (sidx || seg_div > 0));
   if (n == 0) return HOTK_OK;
   HOTK_CHECK_ARG(KV && X && out && ld_x >= (int64_t)HH * c && ld_out >= (int64_t)HH * m && (!XA || ld_xa >= HH));
-  if ((c == 16 || (c == 8 && HOTK_WAVE_C8)) && (ld_x & 3) == 0 && hotk_aligned16(X)) {
+  if ((c == 16 || (c == 8 && HOTK_WAVE_C8)) && (ld_x & 3) == 0 && hotk_aligned16(X) && hotk_aligned16(KV) && m >= 8 && n < (int64_t)0x7fffffff) {
     const int64_t items = ((n + RX_ROWS - 1) / RX_ROWS) * ((HH * m + 63) / 64);
     const dim3 grid(hotk_grid(items, RX_WAVES, 256 * 32)), block(64 * RX_WAVES);
     if (c == 16)
