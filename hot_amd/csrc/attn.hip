@@ -278,61 +278,55 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
     const int h0 = (int)(it - ch * slices) * (64 / C);     // first head of this wave's slice
     const int w = h0 * C + wl, hh = h0 + hl;
     const int64_t pos0 = ch * span + (int64_t)slot * QC_ROWS;
-    // ---- visit records: (row, segment or -1 = zero result, query row, output row or -1 = nothing written)
+    // ---- visit records: (row, segment or -1 = zero result, query row, -); visits past the end repeat the last row
+    // (the same values stored to the same addresses once more)
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
     for (int i = wl; i < QC_ROWS; i += gw) {
-      const int64_t pos = pos0 + i;
-      int4 t = make_int4(-1, -1, -1, -1);
-      if (pos < n) {
-        const int64_t r = order ? (int64_t)order[pos] : pos;
-        const int64_t qr = qidx ? (int64_t)qidx[r] : r;
-        const int64_t sg = seg_of(sidx, seg_div, r);
-        t.x = (int)r;
-        t.z = (int)qr;
-        t.w = oidx ? oidx[r] : (int)r;
-        if (sg >= 0 && qr >= 0 && (!kind || hotk_keep(keep, kind[r]))) t.y = (int)sg;
-      }
+      const int64_t pos = pos0 + i < n ? pos0 + i : n - 1;
+      const int64_t r = order ? (int64_t)order[pos] : pos;
+      const int64_t qr = qidx ? (int64_t)qidx[r] : r;
+      const int64_t sg = seg_of(sidx, seg_div, r);
+      int4 t = make_int4((int)r, -1, (int)qr, 0);
+      if (sg >= 0 && qr >= 0 && (!kind || hotk_keep(keep, kind[r]))) t.y = (int)sg;
       meta[i] = t;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    auto wanted = [&](const int4& t) { return t.y >= 0 && (STATS || t.w >= 0); };
-    float4 qp[QC_PF];
-    float gp[QC_PF];
-#pragma unroll
-    for (int k = 0; k < QC_PF; ++k) {
-      qp[k] = make_float4(0.f, 0.f, 0.f, 0.f);
-      gp[k] = 0.f;
+    // Every global load and store of the row loop is unconditional straight-line code (lanes and rows with nothing to
+    // fetch read the start of KV): loads and stores share one in-order counter, and the compiler waits for "all but the
+    // last k" only when it knows k -- behind a load or store under a branch or an exec mask it waits for everything,
+    // the store of the row before and the prefetches just issued included (see k_row_expand_w).
+    auto q_addr = [&](const int4& t) -> const float* {
+      return (t.y >= 0 && wl < nq4) ? Q + (int64_t)t.z * ld_q + h0 * m + 4 * wl : KV;
+    };
+    auto g_addr = [&](const int4& t) -> const float* { return t.y >= 0 ? dO + (int64_t)t.x * ld_do + w : KV; };
+    // (named registers, not arrays: captured by the step lambda an array stays in scratch memory)
+    float4 qp0, qp1, qp2, qp3;
+    float gp0 = 0.f, gp1 = 0.f, gp2 = 0.f, gp3 = 0.f;
+    auto first = [&](float4& qq, float& gq, const int k) __attribute__((always_inline)) {
       const int4 t = meta[k];
-      if (wanted(t)) {
-        if (wl < nq4) qp[k] = *reinterpret_cast<const float4*>(Q + (int64_t)t.z * ld_q + h0 * m + 4 * wl);
-        if (STATS) gp[k] = dO[(int64_t)t.x * ld_do + w];
-      }
-    }
+      qq = *reinterpret_cast<const float4*>(q_addr(t));
+      if (STATS) gq = *g_addr(t);
+    };
+    first(qp0, gp0, 0); first(qp1, gp1, 1); first(qp2, gp2, 2); first(qp3, gp3, 3);
     float kvn[MM];
 #pragma unroll
     for (int mm = 0; mm < MM; ++mm) kvn[mm] = 0.f;
     int s_cur = -1;
     // every lane runs all QC_ROWS steps: the shuffles below see whole groups.  Groups of QC_PF steps: a step's ring slot
-    // and prefetch registers are compile-time indices (rotating them through moves would wait for the load just issued);
-    // the group loop stays rolled (unrolled, the scheduler parks the records of all 16 steps in registers)
-#pragma unroll 1
-    for (int i0 = 0; i0 < QC_ROWS; i0 += QC_PF)
-#pragma unroll
-    for (int b = 0; b < QC_PF; ++b) {
-      const int i = i0 + b;
+    // and prefetch registers are compile-time (rotating them through moves would wait for the load just issued); the
+    // group loop stays rolled (unrolled, the scheduler parks the records of all 16 steps in registers)
+    auto step = [&](float4& qq, float& gq, const int b, const int i) __attribute__((always_inline)) {
       const int4 t = meta[i];
-      const bool on = wanted(t);
+      const bool on = t.y >= 0;
       float* qrow = ring + b * 256;
-      if (on && wl < nq4) *reinterpret_cast<float4*>(qrow + 4 * wl) = qp[b];
-      const float gv = gp[b];
-      if (i + QC_PF < QC_ROWS) {              // the operands of the row QC_PF steps ahead
-        const int4 u = meta[i + QC_PF];
-        if (wanted(u)) {
-          if (wl < nq4) qp[b] = *reinterpret_cast<const float4*>(Q + (int64_t)u.z * ld_q + h0 * m + 4 * wl);
-          if (STATS) gp[b] = dO[(int64_t)u.x * ld_do + w];
-        }
+      if (wl < nq4) *reinterpret_cast<float4*>(qrow + 4 * wl) = qq;
+      const float gv = gq;
+      {                                       // the operands of the row QC_PF steps ahead (the last group re-reads the last row)
+        const int4 u = meta[i + QC_PF < QC_ROWS ? i + QC_PF : QC_ROWS - 1];
+        qq = *reinterpret_cast<const float4*>(q_addr(u));
+        if (STATS) gq = *g_addr(u);
       }
       float num = 0.f, den = 0.f;
       if (on) {
@@ -342,6 +336,10 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
           for (int mm = 0; mm < MM; ++mm) kvn[mm] = kv[mm * c1 + chn];
           const float* kvs = KV + ((int64_t)t.y * F + h0 * m) * c1 + C;
           for (int f = wl; f < 4 * nq4; f += gw) kvd[f] = kvs[(int64_t)f * c1];
+          // (an opaque use of the column INSIDE the branch: the wait for these loads then sits here, on the rare path;
+          // otherwise it lands in front of the products below as vmcnt(0) and every step waits for its own prefetches)
+#pragma unroll
+          for (int mm = 0; mm < MM; ++mm) asm volatile("" : "+v"(kvn[mm]));
           s_cur = t.y;
         }
       }
@@ -352,33 +350,31 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
         const float* kd = kvd + hl * m;
 #pragma unroll
         for (int mm = 0; mm < MM; mm += 4) {
-            const float4 qv = *reinterpret_cast<const float4*>(qh + mm);
-            const float4 dv = *reinterpret_cast<const float4*>(kd + mm);
-            num = fmaf(qv.x, kvn[mm], num);         den = fmaf(qv.x, dv.x, den);
-            num = fmaf(qv.y, kvn[mm + 1], num);     den = fmaf(qv.y, dv.y, den);
-            num = fmaf(qv.z, kvn[mm + 2], num);     den = fmaf(qv.z, dv.z, den);
-            num = fmaf(qv.w, kvn[mm + 3], num);     den = fmaf(qv.w, dv.w, den);
-            // (an opaque use of den: otherwise the two chains are packed into v_pk_fma_f32, whose operand PAIRS put every
-            // kvn[] into a register pair with a per-step copy of the normaliser value beside it -- 2 m registers and a
-            // v_mov per product; a packed multiply-add takes two issue slots anyway)
-            asm volatile("" : "+v"(den));
-            // (without this the scheduler issues all 2 m / 4 LDS reads of the row first: 88 more registers at m = 44)
-            if ((mm & 4) != 0) __builtin_amdgcn_sched_barrier(0);
-          }
+          const float4 qv = *reinterpret_cast<const float4*>(qh + mm);
+          const float4 dv = *reinterpret_cast<const float4*>(kd + mm);
+          num = fmaf(qv.x, kvn[mm], num);         den = fmaf(qv.x, dv.x, den);
+          num = fmaf(qv.y, kvn[mm + 1], num);     den = fmaf(qv.y, dv.y, den);
+          num = fmaf(qv.z, kvn[mm + 2], num);     den = fmaf(qv.z, dv.z, den);
+          num = fmaf(qv.w, kvn[mm + 3], num);     den = fmaf(qv.w, dv.w, den);
+          // (an opaque use of den: otherwise the two chains are packed into v_pk_fma_f32, whose operand PAIRS put every
+          // kvn[] into a register pair with a per-step copy of the normaliser value beside it -- 2 m registers and a
+          // v_mov per product; a packed multiply-add takes two issue slots anyway)
+          asm volatile("" : "+v"(den));
+          // (without this the scheduler issues all 2 m / 4 LDS reads of the row first: 88 more registers at m = 44)
+          if ((mm & 4) != 0) __builtin_amdgcn_sched_barrier(0);
+        }
       }
       if (!STATS) {
-        if (t.w >= 0) {
-          float o = 0.f;
-          if (on) {
-            if (normalize) {
-              if (den == 0.f) den = 1e-5f;
-              o = num / den;
-            } else {
-              o = num;
-            }
+        float o = 0.f;
+        if (on) {
+          if (normalize) {
+            if (den == 0.f) den = 1e-5f;
+            o = num / den;
+          } else {
+            o = num;
           }
-          out[(int64_t)t.w * ld_out + w] = o;
         }
+        out[(int64_t)t.x * ld_out + w] = o;
       } else {
         // X = dO / den, XA = -(dO . O) / den (k_apply_bwd_stats_c): the channel sum meets through xor shuffles
         float x = 0.f, part = 0.f, inv = 0.f;
@@ -392,11 +388,17 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_contract_w(
         }
 #pragma unroll
         for (int o = 1; o < C; o <<= 1) part += __shfl_xor(part, o, 64);
-        if (t.x >= 0) {
-          out[(int64_t)t.x * ld_out + w] = x;
-          if (chn == 0) XA[(int64_t)t.x * ld_xa + hh] = (on && !guarded) ? -part * inv : 0.f;
-        }
+        out[(int64_t)t.x * ld_out + w] = x;
+        XA[(int64_t)t.x * ld_xa + hh] = (on && !guarded) ? -part * inv : 0.f;     // (all c lanes of the head: same value)
       }
+    };
+    static_assert(QC_PF == 4, "the group below lists its steps");
+#pragma unroll 1
+    for (int i0 = 0; i0 < QC_ROWS; i0 += QC_PF) {
+      step(qp0, gp0, 0, i0);
+      step(qp1, gp1, 1, i0 + 1);
+      step(qp2, gp2, 2, i0 + 2);
+      step(qp3, gp3, 3, i0 + 3);
     }
   }
 }
@@ -410,6 +412,7 @@ bool launch_query_contract_w(hipStream_t st, const float* Q, int64_t ld_q, const
   const int W = HH * c;
   // the feature counts of the shipped head widths: m = int(d log d) = 16 (d = 8), 44 (d = 16); kernel.py:60-63
   if (!HOTK_QC_WAVE || (c != 8 && c != 16) || (m != 16 && m != 44) || m > 4 * c || (ld_q & 3) || !hotk_aligned16(Q)) return false;
+  if (oidx || !hotk_aligned16(KV)) return false;   // (no caller scatters the output rows; KV's start is the dummy address)
   if (n >= (int64_t)0x7fffffff) return false;      // visit records hold 32-bit row ids
   if (!(W <= 64 ? 64 % W == 0 : W % 64 == 0)) return false;
   const int side = W < 64 ? 64 / W : 1, slices = (W + 63) / 64;
