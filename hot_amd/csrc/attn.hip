@@ -625,9 +625,14 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_row_expand_w(
 }
 
 // Key-value sums with a thread per (segment, feature) holding all c + 1 accumulators (c in {8, 16}: ONE walk of the
-// segment, the head's values as 16-byte loads) and the wave's 64 result rows -- one contiguous block of 64 (c + 1) floats
-// -- leaving through an LDS image as c + 1 coalesced stores instead of c + 1 stores with lanes 4 (c + 1) bytes apart.
-// Same fmaf order per accumulator as k_seg_outer_sum: identical bits.
+// segment) and the wave's 64 result rows -- one contiguous block of 64 (c + 1) floats -- leaving through an LDS image
+// as c + 1 coalesced stores instead of c + 1 stores with lanes 4 (c + 1) bytes apart.  The walk is pipelined like
+// k_row_expand_w: the entries' row / key / value indices are fetched 64 at a time, one entry per lane (two dependent
+// round trips per 64 entries instead of three per entry) and handed out with v_readlane; an entry's key value (one float
+// per lane), the heads' value pieces (ONE 16-byte load by the first lanes instead of c / 4 broadcast loads by every
+// lane) and weights are fetched RX_PF entries ahead -- unconditional loads, dummy addresses for lanes and entries that
+// have nothing to fetch, so that the compiler can count them -- and the value pieces pass through a wave-private LDS
+// ring.  Needs m >= 8.  Same fmaf order per accumulator as k_seg_outer_sum: identical bits.
 template <int C>
 __global__ __launch_bounds__(64 * RX_WAVES) void k_seg_outer_sum_w(
     const float* __restrict__ K, int64_t ld_k, const int32_t* __restrict__ kidx, const float* __restrict__ V,
@@ -636,8 +641,10 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_seg_outer_sum_w(
     float* __restrict__ KV, int64_t n_seg, int HH, int m) {
   constexpr int c1 = C + 1;
   __shared__ float img_all[RX_WAVES][64 * c1];
+  __shared__ __align__(16) float ring_all[RX_WAVES][RX_PF][RX_XF];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   float* img = img_all[wave];
+  float* ring = &ring_all[wave][0][0];
   const int F = HH * m, NG = (F + 63) >> 6;
   const int64_t items = n_seg * NG;
   for (int64_t w = (int64_t)blockIdx.x * RX_WAVES + wave; w < items; w += (int64_t)gridDim.x * RX_WAVES) {
@@ -645,31 +652,75 @@ __global__ __launch_bounds__(64 * RX_WAVES) void k_seg_outer_sum_w(
     const int f0 = (int)(w - s * NG) << 6;
     const int nf = F - f0 < 64 ? F - f0 : 64;
     const int f = f0 + (lane < nf ? lane : nf - 1);     // idle lanes shadow the last feature (no divergent loop bounds)
-    const int hh = f / m;
-    const int64_t lo = seg_begin[s], hi = seg_end[s];
+    const int hA = f0 / m, nh = (f0 + nf - 1) / m - hA + 1;     // heads this feature group touches
+    const int hl = f / m - hA;
+    const int nx4 = nh * (C / 4);
+    const int lo = __builtin_amdgcn_readfirstlane(seg_begin[s]), hi = __builtin_amdgcn_readfirstlane(seg_end[s]);
     float acc[c1];
 #pragma unroll
     for (int k = 0; k < c1; ++k) acc[k] = 0.f;
-    for (int64_t p = lo; p < hi; ++p) {
-      const int64_t r = perm ? (int64_t)perm[p] : p;
-      const int64_t kr = kidx ? (int64_t)kidx[r] : r;
-      if (kr < 0) continue;
-      const float kv = K[kr * ld_k + f];
-      const int64_t vr = vidx ? (int64_t)vidx[r] : r;
-      const float va = aug ? aug[r * ld_aug + hh] : 1.f;
-      if (vr >= 0) {
-        const float* vp = V + vr * ld_v + hh * C;
+    for (int base = lo; base < hi; base += 64) {
+      const int cnt = hi - base < 64 ? hi - base : 64;
+      // this batch's entries, one per lane (lanes past the end repeat the last entry)
+      const int p = base + (lane < cnt ? lane : cnt - 1);
+      const int rv = perm ? perm[p] : p;
+      const int krv = kidx ? kidx[rv] : rv;
+      const int vrv = vidx ? vidx[rv] : rv;
+      struct Rec { int r, kr, vr; };
+      auto rec = [&](int i) {        // (i is wave-uniform)
+        const int j = i < cnt ? i : cnt - 1;
+        return Rec{__builtin_amdgcn_readlane(rv, j), __builtin_amdgcn_readlane(krv, j), __builtin_amdgcn_readlane(vrv, j)};
+      };
+      auto k_addr = [&](const Rec& t) -> const float* { return t.kr >= 0 ? K + (int64_t)t.kr * ld_k + f : K; };
+      auto v_addr = [&](const Rec& t) -> const float* {
+        return (t.kr >= 0 && t.vr >= 0 && lane < nx4) ? V + (int64_t)t.vr * ld_v + hA * C + 4 * lane : V;
+      };
+      auto a_addr = [&](const Rec& t) -> const float* {
+        return (aug && t.kr >= 0 && lane < nh) ? aug + (int64_t)t.r * ld_aug + hA + lane : K;
+      };
+      // (named registers, not arrays: captured by the step lambda an array stays in scratch memory)
+      float kq0, kq1, kq2, kq3, aq0, aq1, aq2, aq3;
+      float4 vq0, vq1, vq2, vq3;
+      auto first = [&](float& kq, float4& vq, float& aq, const int i) __attribute__((always_inline)) {
+        const Rec t = rec(i);
+        kq = *k_addr(t);
+        vq = *reinterpret_cast<const float4*>(v_addr(t));
+        aq = *a_addr(t);
+      };
+      first(kq0, vq0, aq0, 0); first(kq1, vq1, aq1, 1); first(kq2, vq2, aq2, 2); first(kq3, vq3, aq3, 3);
+      auto step = [&](float& kq, float4& vq, float& aq, const int b, const int i) __attribute__((always_inline)) {
+        const Rec t = rec(i);
+        float* xs = ring + b * RX_XF;
+        *reinterpret_cast<float4*>(xs + 4 * lane) = vq;      // (the whole stage; lanes past the piece hold dummies)
+        xs[256 + lane] = aug ? aq : 1.f;
+        const float kv = kq;
+        first(kq, vq, aq, i + RX_PF);                         // the entry RX_PF steps ahead (clamped to the batch's last)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (i < cnt && t.kr >= 0) {
+          if (t.vr >= 0) {
+            const float* vh = xs + hl * C;
 #pragma unroll
-        for (int q = 0; q < C / 4; ++q) {
-          const float4 v = *reinterpret_cast<const float4*>(vp + 4 * q);
-          acc[4 * q + 0] = fmaf(kv, v.x, acc[4 * q + 0]); acc[4 * q + 1] = fmaf(kv, v.y, acc[4 * q + 1]);
-          acc[4 * q + 2] = fmaf(kv, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(kv, v.w, acc[4 * q + 3]);
+            for (int q = 0; q < C / 4; ++q) {
+              const float4 v = *reinterpret_cast<const float4*>(vh + 4 * q);
+              acc[4 * q + 0] = fmaf(kv, v.x, acc[4 * q + 0]); acc[4 * q + 1] = fmaf(kv, v.y, acc[4 * q + 1]);
+              acc[4 * q + 2] = fmaf(kv, v.z, acc[4 * q + 2]); acc[4 * q + 3] = fmaf(kv, v.w, acc[4 * q + 3]);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) acc[k] = fmaf(kv, 0.f, acc[k]);
+          }
+          acc[C] = fmaf(kv, xs[256 + hl], acc[C]);
         }
-      } else {
-#pragma unroll
-        for (int k = 0; k < C; ++k) acc[k] = fmaf(kv, 0.f, acc[k]);
+      };
+      static_assert(RX_PF == 4, "the group below lists its steps");
+#pragma unroll 1
+      for (int i0 = 0; i0 < cnt; i0 += RX_PF) {
+        step(kq0, vq0, aq0, 0, i0);
+        step(kq1, vq1, aq1, 1, i0 + 1);
+        step(kq2, vq2, aq2, 2, i0 + 2);
+        step(kq3, vq3, aq3, 3, i0 + 3);
       }
-      acc[C] = fmaf(kv, va, acc[C]);
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -709,7 +760,7 @@ extern "C" int hotk_seg_outer_sum(const float* K, int64_t ld_k, const int32_t* k
   static_assert(AT_CT == 9, "the C8 form keeps 8 values + the normaliser in one tile");
   const bool v16 = (ld_v & 3) == 0 && hotk_aligned16(V);
   // c in {8, 16} with 16-byte aligned value rows: the wave form
-  if ((c == 16 || (c == 8 && HOTK_WAVE_C8)) && v16) {
+  if ((c == 16 || (c == 8 && HOTK_WAVE_C8)) && v16 && m >= 8) {
     const int64_t items = n_seg * ((HH * m + 63) / 64);
     const dim3 grid(hotk_grid(items, RX_WAVES, 256 * 32)), block(64 * RX_WAVES);
     if (c == 16)
