@@ -11,6 +11,10 @@ template <> struct VecT<4> { using type = float4; };
 
 __device__ __forceinline__ float vzero(float) { return 0.f; }
 __device__ __forceinline__ float4 vzero(float4) { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// an opaque use (no instruction): the value must be in registers here
+__device__ __forceinline__ void vtouch(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void vtouch(int& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void vtouch(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
 __device__ __forceinline__ float vadd(float a, float b) { return a + b; }
 __device__ __forceinline__ float4 vadd(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
 __device__ __forceinline__ float vfill(float, float f) { return f; }
@@ -52,7 +56,11 @@ __global__ void k_mask_rows(const float* __restrict__ src, int64_t ld_src, const
 #define HOTK_SEGSUM_UNROLL 8   /* measured at 10 M rows x 288: 2 -> 2.79, 4 -> 2.68, 8 -> 2.56 ms per call */
 #endif
 constexpr int SU = HOTK_SEGSUM_UNROLL;   // entries per step
-template <int V>
+// PERM / KIND: whether the call has a position -> row map and a row-kind filter.  Compile-time, because a load behind
+// a run-time `perm ? perm[p] : p` sits in a block of its own and the compiler waits for it (vmcnt(0)) before the next
+// one is issued: the eight index loads and eight kind loads of a step came out as SIXTEEN dependent round trips instead
+// of two (found in the ISA at the end of round 2; the rows were always fetched together).
+template <int V, bool PERM, bool KIND>
 __global__ void k_seg_sum_rows(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ seg_begin,
                                const int32_t* __restrict__ seg_end, const int32_t* __restrict__ perm,
                                const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out,
@@ -82,24 +90,38 @@ __global__ void k_seg_sum_rows(const float* __restrict__ src, int64_t ld_src, co
     if (lo >= hi && ch > 0) continue;
     T acc = vzero(T());
     // SU entries per step: index, kind and row loads of a step are independent of each other (one latency per
-    // step instead of three per entry); rows past the end re-read the last entry and are not added.  The additions
-    // stay in segment order, so the sum is bitwise the same as the one-at-a-time loop.
+    // step instead of three per entry) and unconditional; rows past the end re-read the last entry and are not added.
+    // The additions stay in segment order, so the sum is bitwise the same as the one-at-a-time loop.
     for (int64_t p = lo; p < hi; p += SU) {
       int64_t r[SU];
-      bool ok[SU];
+      uint8_t kd[SU];
       T v[SU];
+      // (opaque uses of everything fetched: otherwise the compiler sinks a row's loads into the branch that adds it,
+      // or waits for the first index on its own, and the round trips run one after the other)
+      int pr[SU], kk[SU];
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         const int64_t pp = p + u < hi ? p + u : hi - 1;
-        r[u] = perm ? (int64_t)perm[pp] : pp;
+        pr[u] = PERM ? perm[pp] : (int)pp;
       }
 #pragma unroll
-      for (int u = 0; u < SU; ++u) ok[u] = (p + u < hi) && (!kind || hotk_keep(keep, kind[r[u]]));
+      for (int u = 0; u < SU; ++u) {
+        if (PERM) vtouch(pr[u]);
+        r[u] = (int64_t)pr[u];
+      }
+#pragma unroll
+      for (int u = 0; u < SU; ++u) kk[u] = KIND ? (int)kind[r[u]] : 0;
 #pragma unroll
       for (int u = 0; u < SU; ++u) v[u] = *reinterpret_cast<const T*>(src + r[u] * ld_src + cv * V);
 #pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (KIND) vtouch(kk[u]);
+        kd[u] = (uint8_t)kk[u];
+        vtouch(v[u]);
+      }
+#pragma unroll
       for (int u = 0; u < SU; ++u)
-        if (ok[u]) acc = vadd(acc, v[u]);
+        if ((p + u < hi) && (!KIND || hotk_keep(keep, kd[u]))) acc = vadd(acc, v[u]);
     }
     *reinterpret_cast<T*>(out + s * ld_out + cv * V) = acc;
   }
@@ -417,13 +439,23 @@ extern "C" int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t
   // consecutive pieces whose partial rows are summed by a second call (hot_amd.ops.refine_seg), never with atomics
   if (max_seg_len > HOTK_SEG_CHUNK) return HOTK_EUNSUPPORTED;
   const int64_t n_chunk = 1;
-  if (vec4_ok(C, {ld_src, ld_out}, {src, out})) {
-    hipLaunchKernelGGL(k_seg_sum_rows<4>, dim3(hotk_grid(n_seg * n_chunk * (C / 4), 256)), dim3(256), 0, st, src,
-                       ld_src, seg_begin, seg_end, perm, kind, keep, out, ld_out, n_seg, C / 4, n_chunk);
-  } else {
-    hipLaunchKernelGGL(k_seg_sum_rows<1>, dim3(hotk_grid(n_seg * n_chunk * C, 256)), dim3(256), 0, st, src, ld_src,
-                       seg_begin, seg_end, perm, kind, keep, out, ld_out, n_seg, C, n_chunk);
-  }
+  const bool v4 = vec4_ok(C, {ld_src, ld_out}, {src, out});
+  const int64_t CV = v4 ? C / 4 : C;
+  const dim3 grid(hotk_grid(n_seg * n_chunk * CV, 256)), block(256);
+#define HOTK_SEGSUM_LAUNCH(VV, PP, KK)                                                                              \
+  hipLaunchKernelGGL((k_seg_sum_rows<VV, PP, KK>), grid, block, 0, st, src, ld_src, seg_begin, seg_end, perm, kind, \
+                     keep, out, ld_out, n_seg, CV, n_chunk)
+#define HOTK_SEGSUM_PK(VV)                                                    \
+  do {                                                                        \
+    if (perm) {                                                               \
+      if (kind) HOTK_SEGSUM_LAUNCH(VV, true, true); else HOTK_SEGSUM_LAUNCH(VV, true, false);   \
+    } else {                                                                  \
+      if (kind) HOTK_SEGSUM_LAUNCH(VV, false, true); else HOTK_SEGSUM_LAUNCH(VV, false, false); \
+    }                                                                         \
+  } while (0)
+  if (v4) HOTK_SEGSUM_PK(4); else HOTK_SEGSUM_PK(1);
+#undef HOTK_SEGSUM_PK
+#undef HOTK_SEGSUM_LAUNCH
   return hotk_launch_status();
 }
 
