@@ -54,6 +54,9 @@ __global__ void k_assemble22_b(bf16* __restrict__ z, int64_t ld, const float* __
 
 // k_seg_sum_rows (prims.hip) with a bf16 source: rows are added in segment order in fp32, the result rows are fp32
 constexpr int SU = 8;
+// PERM / KIND compile-time and opaque uses of the fetched values, as in prims.hip: the index, kind and row loads of a
+// step are issued together instead of one dependent round trip each
+template <bool PERM, bool KIND>
 __global__ void k_seg_sum_rows_b(const bf16* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ seg_begin,
                                  const int32_t* __restrict__ seg_end, const int32_t* __restrict__ perm,
                                  const uint8_t* __restrict__ kind, unsigned keep, float* __restrict__ out, int64_t ld_out,
@@ -64,21 +67,28 @@ __global__ void k_seg_sum_rows_b(const bf16* __restrict__ src, int64_t ld_src, c
     const int64_t lo = seg_begin[s], hi = seg_end[s];
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int64_t p = lo; p < hi; p += SU) {
-      int64_t r[SU];
-      bool ok[SU];
+      int pr[SU], kk[SU];
       float4 v[SU];
 #pragma unroll
       for (int u = 0; u < SU; ++u) {
         const int64_t pp = p + u < hi ? p + u : hi - 1;
-        r[u] = perm ? (int64_t)perm[pp] : pp;
+        pr[u] = PERM ? perm[pp] : (int)pp;
       }
 #pragma unroll
-      for (int u = 0; u < SU; ++u) ok[u] = (p + u < hi) && (!kind || hotk_keep(keep, kind[r[u]]));
+      for (int u = 0; u < SU; ++u)
+        if (PERM) asm volatile("" : "+v"(pr[u]));
 #pragma unroll
-      for (int u = 0; u < SU; ++u) v[u] = ld4b(src + r[u] * ld_src + cv * 4);
+      for (int u = 0; u < SU; ++u) kk[u] = KIND ? (int)kind[pr[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < SU; ++u) v[u] = ld4b(src + (int64_t)pr[u] * ld_src + cv * 4);
+#pragma unroll
+      for (int u = 0; u < SU; ++u) {
+        if (KIND) asm volatile("" : "+v"(kk[u]));
+        asm volatile("" : "+v"(v[u].x), "+v"(v[u].y), "+v"(v[u].z), "+v"(v[u].w));
+      }
 #pragma unroll
       for (int u = 0; u < SU; ++u)
-        if (ok[u]) acc = add4(acc, v[u]);
+        if ((p + u < hi) && (!KIND || hotk_keep(keep, (uint8_t)kk[u]))) acc = add4(acc, v[u]);
     }
     *reinterpret_cast<float4*>(out + s * ld_out + cv * 4) = acc;
   }
@@ -110,7 +120,15 @@ extern "C" int hotk_seg_sum_rows_bf16(const void* src, int64_t ld_src, const int
   HOTK_CHECK_ARG(src && out && seg_begin && seg_end);
   if (max_seg_len > HOTK_SEG_CHUNK) return HOTK_EUNSUPPORTED;   // as hotk_seg_sum_rows: the caller splits longer segments
   if ((C & 3) || (ld_src & 3) || (ld_out & 3) || !aligned8(src) || !hotk_aligned16(out)) return HOTK_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_seg_sum_rows_b, dim3(hotk_grid(n_seg * (C / 4), 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16*)src, ld_src, seg_begin, seg_end, perm, kind, keep, out, ld_out, n_seg, C / 4);
+  const dim3 grid(hotk_grid(n_seg * (C / 4), 256)), block(256);
+#define HOTK_SSB(PP, KK)                                                                                              \
+  hipLaunchKernelGGL((k_seg_sum_rows_b<PP, KK>), grid, block, 0, (hipStream_t)stream, (const bf16*)src, ld_src, seg_begin, \
+                     seg_end, perm, kind, keep, out, ld_out, n_seg, C / 4)
+  if (perm) {
+    if (kind) HOTK_SSB(true, true); else HOTK_SSB(true, false);
+  } else {
+    if (kind) HOTK_SSB(false, true); else HOTK_SSB(false, false);
+  }
+#undef HOTK_SSB
   return hotk_launch_status();
 }

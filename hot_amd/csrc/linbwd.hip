@@ -115,21 +115,38 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * (32 * LB_WAVES) + wave * 32;
     if (row0 >= R) continue;
-    const float* grow[4];
+    // Every load below is UNCONDITIONAL (rows past the end re-read row R - 1 and are zeroed by a select) and addressed
+    // as G / X / DX + offset: behind `live ? *p : 0` each load sat in a block of its own with a full wait after it, and
+    // an array of row POINTERS went through scratch memory and came back as generic pointers -- flat loads, which
+    // count against the LDS counter as well (found in the ISA at the end of round 2: 13 dependent round trips per
+    // 32-row tile at two waves per SIMD).
+    int64_t goff[4], xoff[4];
     bool live[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t rr = row0 + 8 * i + lr;
       live[i] = rr < R;                                // rows past the end enter as zeros
-      grow[i] = G + (live[i] ? rr : R - 1) * ldg + c_lo + lc;
+      const int64_t rc = live[i] ? rr : R - 1;
+      goff[i] = rc * ldg + c_lo + lc;
+      xoff[i] = rc * ldx + lc;
     }
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // (the zeros of a partial tile -- the last one only -- are written over the staged rows on a wave-uniform branch: a
+    // select on the loaded value is scheduled right behind the load and drags the wait for it in front of the products)
+    const bool partial_tile = __builtin_amdgcn_readfirstlane((int)(row0 + 32 > R)) != 0;
     // x tile -> LDS -> A operands of dW: xa[s] = x[row 2s + half][k = j]
     lb_fence();
+    {
+      float4 t[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float4 t = live[i] ? *reinterpret_cast<const float4*>(X + (row0 + 8 * i + lr) * ldx + lc) : z4;
-      *reinterpret_cast<float4*>(xt + (8 * i + lr) * LB_OS + lc) = t;
+      for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const float4*>(X + xoff[i]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(xt + (8 * i + lr) * LB_OS + lc) = t[i];
+      if (partial_tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!live[i]) *reinterpret_cast<float4*>(xt + (8 * i + lr) * LB_OS + lc) = z4;
+      }
     }
     lb_fence();
     float xa[B6 ? 1 : 16];
@@ -151,7 +168,7 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
     for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
     float4 nx[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nx[i] = live[i] ? *reinterpret_cast<const float4*>(grow[i]) : z4;
+    for (int i = 0; i < 4; ++i) nx[i] = *reinterpret_cast<const float4*>(G + goff[i]);
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       lb_fence();
@@ -161,11 +178,23 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
         *reinterpret_cast<float2*>(d) = make_float2(nx[i].x, nx[i].y);
         *reinterpret_cast<float2*>(d + 2) = make_float2(nx[i].z, nx[i].w);
       }
+      if (partial_tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (!live[i]) {
+            float* d = gt + (8 * i + lr) * LB_GS + lc;
+            *reinterpret_cast<float2*>(d) = make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(d + 2) = make_float2(0.f, 0.f);
+          }
+      }
       lb_fence();
       if (ch + 1 < NCH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) nx[i] = live[i] ? *reinterpret_cast<const float4*>(grow[i] + 32 * (ch + 1)) : z4;
+        for (int i = 0; i < 4; ++i) nx[i] = *reinterpret_cast<const float4*>(G + goff[i] + 32 * (ch + 1));
       }
+      // (the next chunk's loads stay HERE, in front of this chunk's products: at 250 registers the scheduler otherwise
+      // sinks them to just before their use and the wave waits out the whole round trip)
+      __builtin_amdgcn_sched_barrier(0);
       if constexpr (B6) {
         const u32x4* wq = reinterpret_cast<const u32x4*>(lds);
         constexpr int PLQ = NCH * 2 * 32 * 2;            // u32x4 (8 bf16) per plane
@@ -217,17 +246,23 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
       *reinterpret_cast<float4*>(xt + j * LB_OS + 8 * q + 4 * half) =
           make_float4(dxa[4 * q + 0], dxa[4 * q + 1], dxa[4 * q + 2], dxa[4 * q + 3]);
     lb_fence();
+    int64_t doff[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (live[i]) {
-        float4* d = reinterpret_cast<float4*>(DX + (row0 + 8 * i + lr) * lddx + lc);
-        float4 v = *reinterpret_cast<const float4*>(xt + (8 * i + lr) * LB_OS + lc);
-        if (add_dx) {
-          const float4 o = *d;
-          v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-        }
-        *d = v;
-      }
+    for (int i = 0; i < 4; ++i) doff[i] = (live[i] ? row0 + 8 * i + lr : R - 1) * lddx + lc;
+    float4 prev[4];
+    if (add_dx) {                                      // (uniform: the second column half adds to the first's result)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) prev[i] = *reinterpret_cast<const float4*>(DX + doff[i]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) prev[i] = z4;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = *reinterpret_cast<const float4*>(xt + (8 * i + lr) * LB_OS + lc);
+      v.x += prev[i].x; v.y += prev[i].y; v.z += prev[i].z; v.w += prev[i].w;
+      if (live[i]) *reinterpret_cast<float4*>(DX + doff[i]) = v;
+    }
   }
   // partial [34][C] of this wave: dW rows k = (reg & 3) + 8 (reg >> 2) + 4 half, column 32 ch + j; rows 32 + half: column sums
   float* pw = partial + ((int64_t)blockIdx.x * LB_WAVES + wave) * (LB_K + 2) * Ctot + c_lo;
