@@ -229,18 +229,21 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
         // streaming ceiling, and every deeper or wider form of the row stream measured slower -- 8-k pieces 2 / 4 / 6
         // steps ahead 5.5 / 5.1 / 3.3 ms, a lane's 64 contiguous bytes of each line two lines ahead (k order permuted
         // in the weight planes) 3.65 ms, whole lines staged through the result image 9.7 ms.
+        // (two named register sets in turn: with `r = q` at the end of a step the compiler's moves wait for the load
+        // just issued -- vmcnt(0) right behind it in the ISA -- and nothing is ahead at all)
         const float* ap = A + row * lda + 8 * half;
-        float4 r0 = *reinterpret_cast<const float4*>(ap), r1 = *reinterpret_cast<const float4*>(ap + 4);
-#pragma unroll 2
-        for (int ks = 0; ks < KS; ++ks) {
-          const int kn = ks + 1 < KS ? ks + 1 : ks;
-          const float4 q0 = *reinterpret_cast<const float4*>(ap + 16 * kn), q1 = *reinterpret_cast<const float4*>(ap + 16 * kn + 4);
+        auto fetch = [&](int ks, float4& x0, float4& x1) __attribute__((always_inline)) {
+          const int kc = ks < KS ? ks : KS - 1;
+          x0 = *reinterpret_cast<const float4*>(ap + 16 * kc);
+          x1 = *reinterpret_cast<const float4*>(ap + 16 * kc + 4);
+        };
+        auto products = [&](int ks, const float4& x0, const float4& x1) __attribute__((always_inline)) {
           u32x4 bh, bm, bl;
           uint32_t h, m, l;
-          split3_pair(r0.x, r0.y, h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
-          split3_pair(r0.z, r0.w, h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
-          split3_pair(r1.x, r1.y, h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
-          split3_pair(r1.z, r1.w, h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
+          split3_pair(x0.x, x0.y, h, m, l); bh[0] = h; bm[0] = m; bl[0] = l;
+          split3_pair(x0.z, x0.w, h, m, l); bh[1] = h; bm[1] = m; bl[1] = l;
+          split3_pair(x1.x, x1.y, h, m, l); bh[2] = h; bm[2] = m; bl[2] = l;
+          split3_pair(x1.z, x1.w, h, m, l); bh[3] = h; bm[3] = m; bl[3] = l;
 #pragma unroll
           for (int t = 0; t < TG; ++t) {
             const u32x4 wh = wq[((0 * KS + ks) * C + n0 + 32 * t) * 2];
@@ -253,7 +256,20 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
             acc[t] = mfma_bf16(wh, bm, acc[t]);
             acc[t] = mfma_bf16(wh, bh, acc[t]);
           }
-          r0 = q0; r1 = q1;
+        };
+        static_assert(KS % 2 == 0, "the row stream runs in pairs of k steps");
+        float4 r0, r1, q0, q1;
+        fetch(0, r0, r1);
+#pragma unroll 1
+        for (int ks = 0; ks < KS; ks += 2) {
+          // (the barriers keep each request IN FRONT of the other set's products: the scheduler otherwise sinks it to
+          // just before its own use)
+          fetch(ks + 1, q0, q1);
+          __builtin_amdgcn_sched_barrier(0);
+          products(ks, r0, r1);
+          fetch(ks + 2, r0, r1);          // (the last pair re-reads the row's last piece)
+          __builtin_amdgcn_sched_barrier(0);
+          products(ks + 1, q0, q1);
         }
       } else if constexpr (B6) {
 #pragma unroll
