@@ -167,7 +167,44 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
     // per-row epilogue operands: MODE 1 folds the three row kinds into two gathered rows, two multipliers and a bias
     // selector (x2 is zero on diagonal and padding rows, so the accumulator contributes nothing there):
     //   off-diagonal: acc + yn[i][C..) + yn[j][2C..) + b_off    diagonal: 0 + yn[v][0..) + 0 + b_diag    padding: 0
+    float a[B6 ? 1 : KH];
+    constexpr int NF = (B6 && !STREAM) ? KS : 1;
+    u32x4 ah[NF], am[NF], al[NF];   // B6: the lane's B fragments, k = 16 ks + 8 half + (0..7)
+    // the row values are REQUESTED first, then the epilogue's row kinds / node ids (they do not depend on each other:
+    // one round trip for both), then the values are split
+    float4 t0[NF], t1[NF];
+    if constexpr (STREAM) {
+    } else if constexpr (B6) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float* ap = A + row * lda + 16 * ks + 8 * half;
+        t0[ks] = *reinterpret_cast<const float4*>(ap);
+        t1[ks] = *reinterpret_cast<const float4*>(ap + 4);
+      }
+    } else {
+      const float* ap = A + row * lda + half * KH;
+#pragma unroll
+      for (int s = 0; s < KH; s += 4) {
+        const float4 t = *reinterpret_cast<const float4*>(ap + s);
+        a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
+      }
+    }
     RowMeta rm[4];
+    // the twelve kind / node-id loads of a tile are issued together (opaque uses): written as `kd == 2 ? coln[r] : 0` the
+    // column id was fetched under a branch on the kind just loaded -- eight dependent round trips per tile in the ISA
+    int kd4[4] = {0, 0, 0, 0}, rn4[4] = {0, 0, 0, 0}, cn4[4] = {0, 0, 0, 0};
+    if (MODE == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int64_t rr = row0 + 8 * i + er;
+        const int64_t rc = (FULL || rr < R) ? rr : R - 1;
+        kd4[i] = ep.kind[rc];
+        rn4[i] = ep.rown[rc];
+        cn4[i] = ep.coln[rc];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) asm volatile("" : "+v"(kd4[i]), "+v"(rn4[i]), "+v"(cn4[i]));
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int64_t rr = row0 + 8 * i + er;
@@ -177,9 +214,9 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       rm[i].kd = live ? 1 : 0;
       rm[i].pres = nullptr;
       if (MODE == 1) {
-        const int kd = ep.kind[rc];
+        const int kd = kd4[i];
         // padding rows carry node id -1 (plan): they read node row 0 and multiply it by zero
-        const int32_t rn = ep.rown[rc], cn = ep.coln[rc];
+        const int32_t rn = rn4[i], cn = cn4[i];
         const uint32_t yi = (uint32_t)(kd != 0 ? rn : 0) * (uint32_t)ep.ld_yn;
         const uint32_t yj = (uint32_t)(kd == 2 ? cn : 0) * (uint32_t)ep.ld_yn;
         rm[i].o1 = (kd == 2 ? yi + C : yi) + ec;
@@ -189,27 +226,14 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
         rm[i].pres = ep.res + rc * ep.ld_res + ec;
       }
     }
-    float a[B6 ? 1 : KH];
-    constexpr int NF = (B6 && !STREAM) ? KS : 1;
-    u32x4 ah[NF], am[NF], al[NF];   // B6: the lane's B fragments, k = 16 ks + 8 half + (0..7)
-    if constexpr (STREAM) {
-    } else if constexpr (B6) {
+    if constexpr (B6 && !STREAM) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const float* ap = A + row * lda + 16 * ks + 8 * half;
-        const float4 t0 = *reinterpret_cast<const float4*>(ap), t1 = *reinterpret_cast<const float4*>(ap + 4);
         uint32_t h, m, l;
-        split3_pair(t0.x, t0.y, h, m, l); ah[ks][0] = h; am[ks][0] = m; al[ks][0] = l;
-        split3_pair(t0.z, t0.w, h, m, l); ah[ks][1] = h; am[ks][1] = m; al[ks][1] = l;
-        split3_pair(t1.x, t1.y, h, m, l); ah[ks][2] = h; am[ks][2] = m; al[ks][2] = l;
-        split3_pair(t1.z, t1.w, h, m, l); ah[ks][3] = h; am[ks][3] = m; al[ks][3] = l;
-      }
-    } else {
-      const float* ap = A + row * lda + half * KH;
-#pragma unroll
-      for (int s = 0; s < KH; s += 4) {
-        const float4 t = *reinterpret_cast<const float4*>(ap + s);
-        a[s] = t.x; a[s + 1] = t.y; a[s + 2] = t.z; a[s + 3] = t.w;
+        split3_pair(t0[ks].x, t0[ks].y, h, m, l); ah[ks][0] = h; am[ks][0] = m; al[ks][0] = l;
+        split3_pair(t0[ks].z, t0[ks].w, h, m, l); ah[ks][1] = h; am[ks][1] = m; al[ks][1] = l;
+        split3_pair(t1[ks].x, t1[ks].y, h, m, l); ah[ks][2] = h; am[ks][2] = m; al[ks][2] = l;
+        split3_pair(t1[ks].z, t1[ks].w, h, m, l); ah[ks][3] = h; am[ks][3] = m; al[ks][3] = l;
       }
     }
     const float* wl = w_lds + half * KH * C + j;
