@@ -217,6 +217,10 @@ def linear_bwd_ok(R, K, C):
     return R >= THIN_MIN_ROWS and lib().hotk_linear_bwd_supported(int(K), int(C)) == 1
 
 
+def n_rows(t):
+    return t.numel() // t.size(-1)
+
+
 def thin_gemm(A, W, bias=None, res=None):
     """Y[R, C] = A[R, K] @ W[K, C] (+ bias) (+ res) in one pass (hotk_thin_gemm_bias); call thin_ok first"""
     a, lda, R, K = rows2d(A)
@@ -514,7 +518,9 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         dxd = dyn @ Wn.t()
         if dxd_extra is not None:
             dxd += dxd_extra
-        dx2 = g @ W[D:3 * D].t()      # plain products stay library GEMMs: measured on par with the thin kernel
+        # wide-input data gradient [R, C] x [C, 2D]: the thin kernel's row stream since its two-register-set form
+        # (same-box A/B at 10 M rows, C = 288 -> 64: 3.08 ms against 3.46 ms for the library GEMM)
+        dx2 = thin_gemm(g, W[D:3 * D].t()) if (g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)) else g @ W[D:3 * D].t()
         dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
         call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
