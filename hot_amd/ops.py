@@ -5,6 +5,8 @@ kernels.  Each wrapper states which reference code it stands in for.
 """
 from ctypes import byref, c_size_t, c_float, c_int64 as ctypes_long
 
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -211,6 +213,9 @@ def linear_bwd_fused(g, x, w):
          p(dx), K, p(part), R)
     tot = part.sum(0)
     return dx, tot[:K], tot[K] + tot[K + 1]
+
+
+_DWO_FUSED = os.environ.get('HOTK_DWO_FUSED', '1') == '1'
 
 
 def linear_bwd_ok(R, K, C):
@@ -1062,9 +1067,13 @@ class AttnCore22(Function):
         padded = plan.Ev != plan.R
         dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
         datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else dy @ w_o
-        # (the weight-gradient-only mode of hotk_linear_bwd_fused was measured here: 3.65 ms against 3.41 ms for the
-        # split-K batched GEMM at 10 M rows, so the library stays)
-        dw_o = wgrad(dy, att)          # att as saved = the (dropped-out) input of fc_o
+        # att as saved = the (dropped-out) input of fc_o.  dW_o = dy^T . att in the weight-gradient-only mode of
+        # hotk_linear_bwd_fused (x = dy, g = att): 3.65 ms against 3.41 ms for the split-K batched GEMM before that
+        # kernel's loads were made unconditional, measured again after
+        if _DWO_FUSED and dy.dtype == torch.float32 and linear_bwd_ok(plan.R, D, 320):
+            dw_o = linear_bwd_fused(att, dy.contiguous(), None)[1]
+        else:
+            dw_o = wgrad(dy, att)
         db_o = dy.sum(0)
         mu, keep, drop_p = ctx.drop
         AttnCore22._drop_apply(datt, plan, mu, keep, drop_p)
