@@ -50,6 +50,11 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd(const float* __res
 // d == 8, m == 16 (the C1 / C2 head shape), 16-byte aligned rows: a thread keeps its feature's projection row in
 // registers (256 threads = 16 whole heads, so the feature index of a thread never changes) and reads the 8-float head
 // slice as two 16-byte loads shared by the 16 threads of the head.  Same fmaf chain as proj_dot: identical bits.
+// PHI_U (row, feature) items per thread and step, flattened over rows, with the kinds and head slices of all of them
+// requested together and unconditionally (a masked row's slice is fetched and dropped): the block-per-row form paid two
+// dependent round trips per row -- kind, then the slice under a branch on it -- with one row in flight per block
+// (1.27 ms for the 978 k-node key table of the bench: 2.8 TB/s).  Same fmaf chain per element.
+constexpr int PHI_U = 8;
 __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd_8x16(const float* __restrict__ x, int64_t ld_x,
                                                                    const float* __restrict__ proj,
                                                                    const uint8_t* __restrict__ kind, unsigned keep,
@@ -59,27 +64,105 @@ __global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd_8x16(const float* 
   float pr[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) pr[k] = proj[mm * 8 + k];
-  // a block walks whole rows (no 64-bit division per element): f = threadIdx.x, + blockDim.x, ... keeps mm = f & 15
-  const int F = HH * 16;
-  for (int64_t r = blockIdx.x; r < n; r += gridDim.x) {
-    const bool on = !kind || hotk_keep(keep, kind[r]);
-    const float* xr = x + r * ld_x;
-    float* pr_out = phi + r * ld_phi;
-    for (int f = threadIdx.x; f < F; f += PHI_THREADS) {
-      const int hh = f >> 4;
-      float o = 0.f;
-      if (on) {
-        const float4 a = *reinterpret_cast<const float4*>(xr + hh * 8);
-        const float4 b = *reinterpret_cast<const float4*>(xr + hh * 8 + 4);
-        float s = 0.f;
-        s = fmaf(a.x * scale, pr[0], s); s = fmaf(a.y * scale, pr[1], s);
-        s = fmaf(a.z * scale, pr[2], s); s = fmaf(a.w * scale, pr[3], s);
-        s = fmaf(b.x * scale, pr[4], s); s = fmaf(b.y * scale, pr[5], s);
-        s = fmaf(b.z * scale, pr[6], s); s = fmaf(b.w * scale, pr[7], s);
-        o = fmaxf(s, 0.f) + eps;
-      }
-      pr_out[f] = o;
+  const int F = HH * 16;                  // (a multiple of 16 and PHI_THREADS % 16 == 0: item t keeps mm = t & 15)
+  const int64_t total = n * F;
+  const bool small = total < (int64_t)0xffffffffll;
+  const int64_t stride = (int64_t)PHI_THREADS * PHI_U;
+  for (int64_t base = (int64_t)blockIdx.x * stride; base < total; base += (int64_t)gridDim.x * stride) {
+    int64_t r[PHI_U];
+    int f[PHI_U], kd[PHI_U];
+    float4 a[PHI_U], b[PHI_U];
+#pragma unroll
+    for (int u = 0; u < PHI_U; ++u) {
+      const int64_t t = base + threadIdx.x + (int64_t)PHI_THREADS * u;
+      const int64_t tc = t < total ? t : total - 1;
+      r[u] = small ? (int64_t)((uint32_t)tc / (uint32_t)F) : tc / F;
+      f[u] = (int)(tc - r[u] * F);
     }
+#pragma unroll
+    for (int u = 0; u < PHI_U; ++u) kd[u] = kind ? (int)kind[r[u]] : 0;
+#pragma unroll
+    for (int u = 0; u < PHI_U; ++u) {
+      const float* xr = x + r[u] * ld_x + (f[u] >> 4) * 8;
+      a[u] = *reinterpret_cast<const float4*>(xr);
+      b[u] = *reinterpret_cast<const float4*>(xr + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < PHI_U; ++u)     // (opaque uses: the loads stay together, in front of the arithmetic)
+      asm volatile("" : "+v"(kd[u]), "+v"(a[u].x), "+v"(a[u].y), "+v"(a[u].z), "+v"(a[u].w), "+v"(b[u].x), "+v"(b[u].y),
+                   "+v"(b[u].z), "+v"(b[u].w));
+#pragma unroll
+    for (int u = 0; u < PHI_U; ++u) {
+      float s = 0.f;
+      s = fmaf(a[u].x * scale, pr[0], s); s = fmaf(a[u].y * scale, pr[1], s);
+      s = fmaf(a[u].z * scale, pr[2], s); s = fmaf(a[u].w * scale, pr[3], s);
+      s = fmaf(b[u].x * scale, pr[4], s); s = fmaf(b[u].y * scale, pr[5], s);
+      s = fmaf(b[u].z * scale, pr[6], s); s = fmaf(b[u].w * scale, pr[7], s);
+      const bool on = !kind || hotk_keep(keep, (uint8_t)kd[u]);
+      const float o = on ? fmaxf(s, 0.f) + eps : 0.f;
+      if (base + threadIdx.x + (int64_t)PHI_THREADS * u < total) phi[r[u] * ld_phi + f[u]] = o;
+    }
+  }
+}
+
+// A WAVE per row: the row's HH x 8 inputs arrive as ONE coalesced 16-byte load per lane (HH <= 32), pass through a
+// wave-private LDS buffer and are read back as the lane's head slice (two broadcast ds_read_b128 per 64 features).  The
+// block-per-row form had every lane fetch its head's 32 bytes itself -- 16 lanes per address, two 1 KB requests through
+// the texture path per 64 outputs -- and paid two dependent round trips per row (kind, then the slice under a branch on
+// it) with one row in flight per block: 1.27 ms for the 978 k-node key table of the bench (2.3 TB/s), and batching the
+// loads alone changed nothing.  Here the next two rows of a wave are in flight behind the current one (two named
+// register sets, unconditional loads: rows past the end repeat the last row and store the same values again).
+// Needs HH % 4 == 0 and HH <= 32; same fmaf chain per element.
+template <int NGT>      // groups of 64 features per row when known at compile time (the stores of a step are then counted), else 0
+__global__ __launch_bounds__(PHI_THREADS) void k_phi_relu_fwd_8x16_w(const float* __restrict__ x, int64_t ld_x,
+                                                                     const float* __restrict__ proj,
+                                                                     const uint8_t* __restrict__ kind, unsigned keep,
+                                                                     float* __restrict__ phi, int64_t ld_phi, int64_t n,
+                                                                     int HH, float scale, float eps) {
+  constexpr int WAVES = PHI_THREADS / 64;
+  __shared__ __align__(16) float xs_all[WAVES][2][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, mm = lane & 15;
+  float pr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) pr[k] = proj[mm * 8 + k];
+  const int nq = HH * 2, NG = NGT ? NGT : HH >> 2;          // 16-byte pieces of a row; groups of 64 features
+  const int lq = lane < nq ? lane : 0;          // (idle lanes re-read piece 0)
+  const int64_t stride = (int64_t)gridDim.x * WAVES;
+  const uint8_t* kbase = kind ? kind : reinterpret_cast<const uint8_t*>(proj);
+  auto fetch = [&](int64_t r, float4& v, int& kd) __attribute__((always_inline)) {
+    const int64_t rc = r < n ? r : n - 1;
+    v = *reinterpret_cast<const float4*>(x + rc * ld_x + 4 * lq);
+    kd = (int)kbase[kind ? rc : 0];       // (unconditional: a load under `kind ? ... : 0` cannot be counted)
+  };
+  auto step = [&](float4& v, int& kd, const int b, const int64_t r) __attribute__((always_inline)) {
+    const int64_t rc = r < n ? r : n - 1;
+    float* xs = xs_all[wave][b];
+    *reinterpret_cast<float4*>(xs + 4 * lane) = v;
+    const bool on = !kind || hotk_keep(keep, (uint8_t)kd);
+    fetch(r + 2 * stride, v, kd);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    float* out = phi + rc * ld_phi + lane;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      const float* xh = xs + (4 * g + (lane >> 4)) * 8;
+      const float4 a = *reinterpret_cast<const float4*>(xh), c = *reinterpret_cast<const float4*>(xh + 4);
+      float t = 0.f;
+      t = fmaf(a.x * scale, pr[0], t); t = fmaf(a.y * scale, pr[1], t);
+      t = fmaf(a.z * scale, pr[2], t); t = fmaf(a.w * scale, pr[3], t);
+      t = fmaf(c.x * scale, pr[4], t); t = fmaf(c.y * scale, pr[5], t);
+      t = fmaf(c.z * scale, pr[6], t); t = fmaf(c.w * scale, pr[7], t);
+      out[64 * g] = on ? fmaxf(t, 0.f) + eps : 0.f;
+    }
+  };
+  int64_t r = (int64_t)blockIdx.x * WAVES + wave;
+  float4 v0, v1;
+  int k0, k1;
+  fetch(r, v0, k0);
+  fetch(r + stride, v1, k1);
+  for (; r < n; r += 2 * stride) {
+    step(v0, k0, 0, r);
+    step(v1, k1, 1, r + stride);
   }
 }
 
@@ -618,8 +701,16 @@ extern "C" int hotk_phi_fwd(const float* x, int64_t ld_x, const float* proj, con
   hipStream_t st = (hipStream_t)stream;
   const float scale = powf((float)d, -0.25f);
   if (mode == HOTK_PHI_RELU && d == 8 && m == 16 && (ld_x & 3) == 0 && ((uintptr_t)x & 15) == 0) {
-    hipLaunchKernelGGL(k_phi_relu_fwd_8x16, dim3(hotk_grid(n, 1, 256 * 32)), dim3(PHI_THREADS), 0, st, x,
-                       ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
+    if ((HH & 3) == 0 && HH <= 32 && (ld_x & 3) == 0 && hotk_aligned16(x)) {
+      if (HH == 32)
+        hipLaunchKernelGGL(k_phi_relu_fwd_8x16_w<8>, dim3(hotk_grid(n, PHI_THREADS / 64, 256 * 8)), dim3(PHI_THREADS), 0, st, x,
+                           ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
+      else
+        hipLaunchKernelGGL(k_phi_relu_fwd_8x16_w<0>, dim3(hotk_grid(n, PHI_THREADS / 64, 256 * 8)), dim3(PHI_THREADS), 0, st, x,
+                           ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
+    } else
+      hipLaunchKernelGGL(k_phi_relu_fwd_8x16, dim3(hotk_grid(n * HH * 16, PHI_THREADS * PHI_U, 256 * 32)), dim3(PHI_THREADS), 0, st, x,
+                         ld_x, proj, kind, keep, phi, ld_phi, n, HH, scale, 1e-3f);
   } else if (mode == HOTK_PHI_RELU && phi_vec_ok(x, ld_x, d, m)) {
     const dim3 grid(hotk_grid(n, 1, 256 * 32)), block(PHI_THREADS);
     switch (d) {
