@@ -226,8 +226,8 @@ def edge_shard_mode(args, device, world, rank, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--entries', type=float, default=10e6, help='entries per GPU')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-kernel', default='auto', help='C-ABI entry point timed live with HIP events')
