@@ -875,3 +875,36 @@ def test_general_attention_kernels_masks_and_indices(HH, m, c):
     n1 = n_src
     rE1 = np.einsum('rhmc,rhc->rhm', KVn[np.arange(n1) // 13][:, :, :, :c], Xn[:n1]) + KVn[np.arange(n1) // 13][:, :, :, c]
     assert rel_err(E1, f32(rE1, n1, F)) < TOL
+
+
+@pytest.mark.parametrize('HH,d,m', [(32, 8, 16), (12, 8, 16), (6, 8, 16), (64, 8, 16), (24, 16, 44), (3, 16, 44), (80, 16, 44),
+                                    (8, 32, 110), (5, 4, 5)])
+def test_relu_feature_map_every_dispatch_path(HH, d, m):
+    """hotk_phi_fwd / hotk_phi_bwd (ReLU map; models/common/kernel.py:81-100 + the loop / padding masks of
+    kernelattncoef.py:19-28) at head counts that take each kernel of csrc/phi.hip: the 8 x 16 wave-per-row kernel with a
+    compile-time and a run-time group count, its flattened fallback (head counts that are no multiple of 4, or more than
+    32 heads), the wave-per-row kernel for d in {8, 16, 32}, the block-per-row kernel (rows wider than the wave's LDS
+    row) and the generic one -- against fp64 numpy, on rows of a wider tensor and with masked rows."""
+    from hot_amd import ops, _lib
+    g = torch.Generator().manual_seed(HH * 1000 + d * 10 + m)
+    n = 777
+    xw = torch.randn(n, HH * d + 8, generator=g)
+    x = xw[:, 4:4 + HH * d]                                   # 16-byte aligned rows of a wider tensor
+    proj = torch.randn(m, d, generator=g)
+    kind = torch.randint(0, 3, (n,), generator=g).to(torch.uint8)
+    xd = xw.to(DEV)[:, 4:4 + HH * d].requires_grad_(True)
+    out = ops.Phi.apply(xd, proj.to(DEV), kind.to(DEV), _lib.KEEP_OFFDIAG, d, _lib.PHI_RELU)
+    w = torch.randn(n, HH * m, generator=g)
+    (out * w.to(DEV)).sum().backward()
+    xn = x.double().numpy().reshape(n, HH, d) * d ** -0.25
+    pre = np.einsum('nhd,md->nhm', xn, proj.double().numpy())
+    on = (kind.numpy() == 2)[:, None, None]
+    ref = np.where(on, np.maximum(pre, 0.0) + 1e-3, 0.0).reshape(n, HH * m)
+    gate = np.where(on & (pre > 0), w.double().numpy().reshape(n, HH, m), 0.0)
+    dref = np.einsum('nhm,md->nhd', gate, proj.double().numpy()).reshape(n, HH * d) * d ** -0.25
+    assert rel_err(out.detach().cpu(), torch.from_numpy(ref).float()) < TOL
+    assert float(out.detach()[kind.to(DEV) != 2].abs().max()) == 0.0
+    # a pre-activation within rounding of zero may gate differently in fp32: compare where |pre| is not tiny
+    safe = (np.abs(pre) > 1e-5).all(axis=(1, 2))
+    dx = xd.grad.cpu()
+    assert rel_err(dx[torch.from_numpy(safe)], torch.from_numpy(dref[safe]).float()) < TOL
