@@ -95,7 +95,8 @@ int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* 
                         int64_t n, int64_t C, void* stream);
 /* db_off[c] = sum over kind-2 rows of dy, db_diag[c] = sum over kind-1 rows (either may be NULL): gradients of the two
  * _Bias vectors (models/sparse/linear.py:293-306).  Two passes (per-block partial rows in the workspace, then added in
- * block order): bitwise reproducible, no atomics; outputs are overwritten.
+ * a fixed order: 16 interleaved slices of the block sequence, then the slices): bitwise reproducible, no atomics;
+ * outputs are overwritten.
  * workspace: hotk_bias_grad_workspace_bytes(n, C). */
 int hotk_bias_grad_workspace_bytes(int64_t n, int64_t C, size_t* bytes);
 int hotk_bias_grad_rows(const float* dy, int64_t ld, const uint8_t* kind, float* db_off, float* db_diag,
