@@ -401,12 +401,15 @@ int launch_v(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy,
   return hotk_launch_status();
 }
 
-// the variants in use: a residual only with MODE 0, bf16 results only from the entry GEMM (MODE 1)
+// the variants in use: a residual only with MODE 0, bf16 results from the entry GEMM (MODE 1) and the K = 32 products
 template <int KH, int TG, int MODE, int NW = 8, bool B6 = false>
 int launch(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
            hipStream_t st) {
   if constexpr (MODE == 0) {
-    if (ep.out_bf16) return HOTK_EUNSUPPORTED;
+    if (ep.out_bf16) {   // bf16 results without a residual: the narrow-to-wide products of the bf16 storage mode (fc_v, d att)
+      if (ep.res || KH != 16) return HOTK_EUNSUPPORTED;
+      if constexpr (KH == 16) return launch_v<KH, TG, MODE, NW, B6, false, true>(A, lda, W, Y, ldy, R, C, ep, st);
+    }
     return ep.res ? launch_v<KH, TG, MODE, NW, B6, true, false>(A, lda, W, Y, ldy, R, C, ep, st)
                   : launch_v<KH, TG, MODE, NW, B6, false, false>(A, lda, W, Y, ldy, R, C, ep, st);
   } else {
@@ -477,6 +480,20 @@ extern "C" int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, 
   Epi ep{};
   ep.bias = bias; ep.res = res; ep.ld_res = ld_res;
   return dispatch<0>(A, lda, W, K, C, Y, ldy, R, ep, (hipStream_t)stream);
+}
+
+// the same product with the result rounded to bf16 at the store (K = 32 only: fc_v and d att of the bf16 storage mode)
+extern "C" int hotk_thin_gemm_bias_bf16(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
+                                        void* Y, int64_t ldy, int64_t R, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && K > 0 && C > 0 && lda >= K && ldy >= C);
+  if (K != 32 || !shape_ok(K, C)) return HOTK_EUNSUPPORTED;
+  if (R == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(A && W && Y && hotk_aligned16(A) && hotk_aligned16(W) && (lda & 3) == 0);
+  HOTK_CHECK_ARG((((uintptr_t)Y) & 7u) == 0 && (ldy & 3) == 0 && (!bias || hotk_aligned16(bias)));
+  Epi ep{};
+  ep.bias = bias;
+  ep.out_bf16 = 1;
+  return dispatch<0>(A, lda, W, K, C, (float*)Y, ldy, R, ep, (hipStream_t)stream);
 }
 
 namespace {

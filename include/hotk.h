@@ -166,6 +166,10 @@ int hotk_basis22_full_bwd_gather(const float* w, int64_t ld_w, const uint8_t* ki
 int hotk_thin_gemm_supported(int64_t K, int64_t C);
 int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
                         const float* res, int64_t ld_res, float* Y, int64_t ldy, int64_t R, void* stream);
+/* The K = 32 product with the result rounded to bf16 at the store (Y: bf16 rows, 8-byte aligned, ldy % 4 == 0): fc_v
+ * and d att = d y . W_o of the bf16 storage mode (models/sparse/kernelattn.py:51,65-72 at the north_star's 2e-2). */
+int hotk_thin_gemm_bias_bf16(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
+                             void* Y, int64_t ldy, int64_t R, void* stream);
 int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
                             int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
                             const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R, int64_t Nn, void* stream);
