@@ -34,6 +34,12 @@ class Batch(object):
         else:
             self.mask = mask if mask is not None else _size_mask(n_edges, dev)
         self._plan = None
+        # a batch whose graphs all fill the padded width has no invalid rows: the zero-filling pass (a full copy of the
+        # values) is skipped for it and for every batch derived from it (batch_like copies the flag)
+        # (only when the mask was derived from the sizes here: a mask handed in by the caller is taken as it is)
+        sizes = n_nodes if order == 1 else n_edges
+        own_mask = (node_mask is None) if order == 1 else (mask is None)
+        self._padded = (not own_mask) or sizes is None or any(int(s_) != self.mask.size(1) for s_ in sizes)
         # zero-filling of invalid rows happens on the device (HIP kernel); a host-side batch remembers that it is due
         self._pending_mask = False
         if not skip_masking:
@@ -47,7 +53,8 @@ class Batch(object):
 
     def _mask_now_or_later(self):
         if self.values.is_cuda:
-            self.apply_mask(0)
+            if getattr(self, '_padded', True):
+                self.apply_mask(0)
         else:
             self._pending_mask = True
 
