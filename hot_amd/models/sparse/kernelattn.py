@@ -70,11 +70,17 @@ class KernelSelfAttn(nn.Module):
         nn.init.constant_(self.fc_o.bias, 0.)
 
     # -- helpers ------------------------------------------------------------------------------------
-    def _phi_slots(self, H: B, lo, hi, is_query):
-        """feature-map the dim_qk-wide slots [lo, hi) of H.values and return them as a list of batches"""
+    def _phi_slots(self, H: B, lo, hi, is_query, groups=None):
+        """feature-map the dim_qk-wide slots [lo, hi) of H.values and return them as a list of batches, one per slot --
+        or one per GROUP of adjacent slots (groups = slot counts): slots that one attention call takes as a list arrive
+        already side by side, as a view, instead of being concatenated again (a full copy of both)"""
         x = batch_like(H, H.values[..., lo * self.dim_qk:hi * self.dim_qk], skip_masking=True)
         phi = self.feature_map(x, is_query=is_query)
-        return [batch_like(H, v, skip_masking=True) for v in phi.values.split(self.feat_dim * self.n_heads, -1)]
+        F = self.feat_dim * self.n_heads
+        if groups is None:
+            return [batch_like(H, v, skip_masking=True) for v in phi.values.split(F, -1)]
+        assert sum(groups) == hi - lo
+        return [batch_like(H, v, skip_masking=True) for v in phi.values.split([g * F for g in groups], -1)]
 
     def _values(self, G: B):
         v = batch_like(G, self.fc_v(G.values), skip_masking=False)
@@ -103,17 +109,17 @@ class KernelSelfAttn(nn.Module):
     def _2_to_1(self, G: B):
         h_1 = self.fc_1(G)
         non_att = batch_like(h_1, h_1.values[..., -self.dim_in:], skip_masking=True)
-        q_1 = self._phi_slots(h_1, 0, 4, True)
-        k_1 = self._phi_slots(h_1, 4, 7, False)
+        q_1 = self._phi_slots(h_1, 0, 4, True, groups=(2, 1, 1))       # [slots 0-1 | 2 | 3]
+        k_1 = self._phi_slots(h_1, 4, 7, False, groups=(2, 1))         # [slots 0-1 | 2]
         h_2 = self.fc_2(G)
         k_2 = self._phi_slots(h_2, 0, 1, False)[0]
         v = self._values(G)
         # graph -> set:  O_j = Q_j . sum_i K_i (x) V_ij   for V and V^T
-        att = list(self.att_1_1(q_1[0:2], k_1[0:2], [v[0], t(v[1])], diagonal=(1, 2)))
+        att = list(self.att_1_1(q_1[0], k_1[0], [v[0], t(v[1])], diagonal=(1, 2)))
         if not self.is_local:
-            att.append(self.att_1_1(q_1[2], k_1[2], d(v[2])))      # set -> set (global)
-            att.append(self.att_1_2(q_1[3], k_2, v[3]))            # graph -> set (global)
-        return add_batch(non_att, self._project_out(q_1[0], att))
+            att.append(self.att_1_1(q_1[1], k_1[1], d(v[2])))      # set -> set (global)
+            att.append(self.att_1_2(q_1[2], k_2, v[3]))            # graph -> set (global)
+        return add_batch(non_att, self._project_out(h_1, att))
 
     def _fused_ok(self):
         """the fused attention core covers the headline shape: 4 heads x 16 features (one wavefront per slot),
@@ -148,22 +154,23 @@ class KernelSelfAttn(nn.Module):
             return batch_like(G, out, skip_masking=True)
         h_2 = self.fc_2(G)                      # [B, |E|, 8 dqk + D]: 6 query slots, 2 key slots, skip path
         non_att = batch_like(h_2, h_2.values[..., -self.dim_in:], skip_masking=True)
-        q_1 = self._phi_slots(h_1, 0, 4, True)
-        k_1 = self._phi_slots(h_1, 4, 12, False)
-        q_2 = self._phi_slots(h_2, 0, 6, True)
+        # slots that one attention call takes as a pair stay side by side (views of the feature-map output)
+        q_1 = self._phi_slots(h_1, 0, 4, True, groups=(2, 1, 1))             # [0-1 | 2 | 3]
+        k_1 = self._phi_slots(h_1, 4, 12, False, groups=(2, 2, 2, 1, 1))     # [0-1 | 2-3 | 4-5 | 6 | 7]
+        q_2 = self._phi_slots(h_2, 0, 6, True, groups=(2, 2, 1, 1))          # [0-1 | 2-3 | 4 | 5]
         k_2 = self._phi_slots(h_2, 6, 8, False)
         v = self._values(G)
         # node outputs from column-segmented sums, placed on the diagonal
-        a1, a2 = self.att_1_1(q_1[0:2], k_1[0:2], [v[0], t(v[1])], diagonal=(1, 2))
+        a1, a2 = self.att_1_1(q_1[0], k_1[0], [v[0], t(v[1])], diagonal=(1, 2))
         # entry outputs reading the column sum (a3, a5) or the row-node's sum (a4, a6)
-        a3, a5 = self.att_2_1(q_2[0:2], k_1[2:4], [v[2], t(v[3])], diagonal=(2, 3))
-        a4, a6 = self.att_2_1(q_2[2:4], k_1[4:6], [t(v[4]), v[5]], diagonal=(1, 3))
+        a3, a5 = self.att_2_1(q_2[0], k_1[1], [v[2], t(v[3])], diagonal=(2, 3))
+        a4, a6 = self.att_2_1(q_2[1], k_1[2], [t(v[4]), v[5]], diagonal=(1, 3))
         att = [v2d(G, a1), v2d(G, a2), a3, a4, a5, a6]
         if not self.is_local:
-            att.append(v2d(G, self.att_1_1(q_1[2], k_1[6], d(v[6]))))    # set -> set
-            att.append(v2d(G, self.att_1_2(q_1[3], k_2[0], v[7])))       # graph -> set
-            att.append(self.att_2_1(q_2[4], k_1[7], d(v[8])))            # set -> graph
-            att.append(self.att_2_2(q_2[5], k_2[1], v[9]))               # graph -> graph
+            att.append(v2d(G, self.att_1_1(q_1[1], k_1[3], d(v[6]))))    # set -> set
+            att.append(v2d(G, self.att_1_2(q_1[2], k_2[0], v[7])))       # graph -> set
+            att.append(self.att_2_1(q_2[2], k_1[4], d(v[8])))            # set -> graph
+            att.append(self.att_2_2(q_2[3], k_2[1], v[9]))               # graph -> graph
         return add_batch(non_att, self._project_out(G, att))
 
     def forward(self, G: B):

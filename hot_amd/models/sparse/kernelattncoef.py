@@ -58,7 +58,10 @@ class KernelAttnCoef(nn.Module):
         O_j = Q_j.KV_j, O_ij = Q_ij.KV_j (dim1 = 2) or O_ij = Q_ij.KV_i (dim1 = 1).
         Lists of S tuples are run as S*H heads in one pass and split back."""
         as_list = isinstance(value, list)
-        qs, ks, vs = (query, key, value) if as_list else ([query], [key], [value])
+        vs = value if as_list else [value]
+        # queries / keys of a list call may also arrive as ONE batch with the S slots already side by side
+        qs = query if isinstance(query, list) else [query]
+        ks = key if isinstance(key, list) else [key]
         q0, k0, v0 = qs[0], ks[0], vs[0]
         assert isinstance(q0, B) and isinstance(k0, B) and isinstance(v0, B)
         assert q0.order == self.ord_q and k0.order == self.ord_k
