@@ -1,6 +1,11 @@
 """Headline benchmark: entries/s forward+backward of the 2->2 sparse kernel-attention layer (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: when no launcher has set WORLD_SIZE, this process (which never touches the GPU) starts the N ranks itself as
+children of `python -m torch.distributed.run` (one per GPU, RCCL), forwards rank 0's JSON line and exits with the
+launcher's return code -- the stand-in for Lightning's DDP launcher of regression/main/entry.py:110-113.  Launched
+from outside by torch.distributed.run it runs as one rank, as before.
 
 Workload "S1/C1" (SURVEY 8d): B Barabasi-Albert(64, 5) graphs -> 654 entries each (64 diagonal + 590 directed
 edges), ~10 M entries per GPU; layer KernelSelfAttn(2,2, dim_in=32, dim_v=32, dim_qk=32, n_heads=4) with the
@@ -223,6 +228,56 @@ def edge_shard_mode(args, device, world, rank, dist):
         }), flush=True)
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n, argv):
+    """Parent of an N-rank run: start `python -m torch.distributed.run --nproc-per-node N bench.py <argv>` as a CHILD
+    process (never an exec: this parent may live on, the children initialise the GPUs), pass rank 0's JSON line through
+    on stdout, everything else to stderr; returns the launcher's exit code (non-zero when any rank failed).  The parent
+    makes no device call and loads no HIP library."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, min(16, (os.cpu_count() or 1) // n))))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True, bufsize=1)
+    lines = 0
+    for ln in proc.stdout:
+        if ln.startswith('{') and ln.rstrip().endswith('}'):
+            sys.stdout.write(ln)
+            sys.stdout.flush()
+            lines += 1
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if rc == 0 and lines == 0:
+        sys.stderr.write('bench.py: the ranks exited cleanly but rank 0 printed no result line\n')
+        rc = 1
+    return rc
+
+
+def dry_launch(args, world, rank, dist):
+    """HOTK_BENCH_DRY_LAUNCH=1: the N > 1 start-up path up to (not including) device selection -- rendezvous, one MAX
+    all-reduce (the timing reduction of the real run), rank 0's line -- so that the launcher is testable without a GPU."""
+    from hot_amd.dist import max_over_ranks
+    slowest = max_over_ranks(float(rank + 1), 'cpu')
+    if dist is not None:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({'metric': 'dry-launch', 'n_gpus': world, 'gpus_arg': args.gpus, 'slowest_rank_plus_1': slowest,
+                          'mode': args.mode}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -244,21 +299,34 @@ def main():
     if os.environ.get('HOTK_BENCH_DEBUG'):
         import faulthandler
         faulthandler.dump_traceback_later(int(os.environ['HOTK_BENCH_DEBUG']), exit=True)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus in the result '
+                         f'line must equal --gpus')
+    dry = os.environ.get('HOTK_BENCH_DRY_LAUNCH') == '1'
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         # one rank per GPU over RCCL; HOTK_BENCH_BACKEND=gloo rehearses the N > 1 code path on a box with fewer GPUs
-        backend = os.environ.get('HOTK_BENCH_BACKEND', 'nccl')
+        backend = 'gloo' if dry else os.environ.get('HOTK_BENCH_BACKEND', 'nccl')
+        if dry:
+            dist.init_process_group(backend)
+            return dry_launch(args, world, rank, dist)
+        if backend == 'nccl' and torch.cuda.device_count() < world:
+            raise SystemExit(f'bench.py: {world} RCCL ranks need {world} GPUs, this node shows {torch.cuda.device_count()}')
         local_rank = local_rank % max(torch.cuda.device_count(), 1) if backend != 'nccl' else local_rank
         torch.cuda.set_device(local_rank)
         if backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
             dist.init_process_group(backend)
+    if dry:
+        return dry_launch(args, world, rank, None)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
