@@ -3,6 +3,7 @@
 One object per csrc/*.hip (compiled in parallel, only when the source or a header is newer), linked into
 hot_amd/libhotk.so.  Objects live under hot_amd/csrc/_obj/ (git-ignored)."""
 import glob
+import hashlib
 import os
 import subprocess
 import sys
@@ -30,6 +31,12 @@ def build(force=False, verbose=True, extra_flags=(), out=OUT):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     tag = '' if out == OUT else '.' + os.path.basename(out)
     os.makedirs(OBJ, exist_ok=True)
+    # objects are reused only when they were compiled by the same compiler with the same flags: the stamp holds a hash
+    # of (hipcc, FLAGS + extra_flags), so an A/B build with other flags under the same name never measures stale code
+    cfg = hashlib.sha256('\0'.join([hipcc] + FLAGS + list(extra_flags)).encode()).hexdigest()
+    stamp = os.path.join(OBJ, 'flags' + tag + '.stamp')
+    if not os.path.exists(stamp) or open(stamp).read() != cfg:
+        force = True
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + tag + '.o')
@@ -46,7 +53,10 @@ def build(force=False, verbose=True, extra_flags=(), out=OUT):
 
     with ThreadPoolExecutor(max_workers=min(8, max(len(jobs), 1))) as ex:
         list(ex.map(run, jobs))
-    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + objs)
+    link_extra = [f for f in extra_flags if f.startswith(('-L', '-l', '-Wl,', '-fsanitize', '-g'))]
+    run([hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', out] + link_extra + objs)
+    with open(stamp, 'w') as f:
+        f.write(cfg)
     return out
 
 

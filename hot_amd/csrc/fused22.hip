@@ -1772,19 +1772,42 @@ constexpr int MAX_DEVICES = 64;
 std::mutex scratch_mu;
 void* scratch_ptr[MAX_DEVICES];   // per device, filled on the first call with that device current
 
-int static_scratch(float** out) {
-  int dev = -1;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return HOTK_ELAUNCH;
+// the array's address on `dev`: looked up once per device, with that device current
+int static_scratch_on(int dev, float** out) {
+  if (dev < 0 || dev >= MAX_DEVICES) return HOTK_ELAUNCH;
   std::lock_guard<std::mutex> lock(scratch_mu);
   if (!scratch_ptr[dev]) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) return HOTK_ELAUNCH;
+    if (cur != dev && hipSetDevice(dev) != hipSuccess) return HOTK_ELAUNCH;
     void* ptr = nullptr;
-    if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return HOTK_ELAUNCH;
+    const hipError_t e = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (cur != dev && hipSetDevice(cur) != hipSuccess) return HOTK_ELAUNCH;
+    if (e != hipSuccess || !ptr) return HOTK_ELAUNCH;
     scratch_ptr[dev] = ptr;
   }
-  *out = (float*)scratch_ptr[dev];
+  if (out) *out = (float*)scratch_ptr[dev];
   return HOTK_OK;
 }
+// the device a launch on `stream` runs on: the stream's own device, or the current one for the null stream
+int stream_device(hipStream_t st, int* dev) {
+  if (st) {
+    hipDevice_t d;
+    if (hipStreamGetDevice(st, &d) == hipSuccess) {
+      *dev = (int)d;
+      return HOTK_OK;
+    }
+    (void)hipGetLastError();
+  }
+  return hipGetDevice(dev) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
+}
 }  // namespace
+
+extern "C" int hotk_attn22_static_init(void) {
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess) return HOTK_ELAUNCH;
+  return static_scratch_on(dev, nullptr);
+}
 
 extern "C" int hotk_attn22_forward_static(const hotk_attn22_args* a, void* stream) {
   int rc = check_args(a);
@@ -1795,9 +1818,14 @@ extern "C" int hotk_attn22_forward_static(const hotk_attn22_args* a, void* strea
   if (need > STATIC_SCRATCH_BYTES) return HOTK_ETOOLARGE;
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
   float* part = nullptr;
-  rc = static_scratch(&part);
+  int dev = -1;
+  rc = stream_device((hipStream_t)stream, &dev);
   if (rc) return rc;
-  return attn22_forward_launch(a, part, ws_tickets(a, part, need), (hipStream_t)stream);
+  rc = static_scratch_on(dev, &part);   // a cached pointer after hotk_attn22_static_init / the first call on this device
+  if (rc) return rc;
+  // static stride, no work tickets: a batch that fits the array is far below the size where tickets pay (ws_tickets), and
+  // without them the array needs no clearing between calls
+  return attn22_forward_launch(a, part, nullptr, (hipStream_t)stream);
 }
 
 namespace {

@@ -249,6 +249,9 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
     int64_t doff[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) doff[i] = (live[i] ? row0 + 8 * i + lr : R - 1) * lddx + lc;
+    // Rows past the end of a partial tile (the dead lanes) load DX row R - 1 while the live lane of that row in the same
+    // tile stores to it: a benign race on an output buffer -- the loaded value is discarded (the store below is under
+    // live[i]); the clamp only keeps the load stream unconditional and on a valid address.
     float4 prev[4];
     if (add_dx) {                                      // (uniform: the second column half adds to the first's result)
 #pragma unroll
@@ -264,14 +267,29 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
       if (live[i]) *reinterpret_cast<float4*>(DX + doff[i]) = v;
     }
   }
-  // partial [34][C] of this wave: dW rows k = (reg & 3) + 8 (reg >> 2) + 4 half, column 32 ch + j; rows 32 + half: column sums
-  float* pw = partial + ((int64_t)blockIdx.x * LB_WAVES + wave) * (LB_K + 2) * Ctot + c_lo;
+  // The eight waves of the workgroup add their dW / column-sum registers in LDS, in wave order (fixed: reproducible), and
+  // the workgroup leaves ONE partial [34][C] block: dW rows k = (reg & 3) + 8 (reg >> 2) + 4 half, column 32 ch + j; rows
+  // 32 + half: column sums of the even / odd rows.  (One block per wave was 2 048 blocks = 89 MB for the caller to sum.)
+  __syncthreads();                                     // every wave is done with the staging rows: LDS is reused from 0
+  float* acc = lds;                                    // [34][C]
+#pragma unroll 1
+  for (int w = 0; w < LB_WAVES; ++w) {
+    if (wave == w) {
 #pragma unroll
-  for (int ch = 0; ch < NCH; ++ch) {
+      for (int ch = 0; ch < NCH; ++ch) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pw[((r & 3) + 8 * (r >> 2) + 4 * half) * Ctot + 32 * ch + j] = dw[ch][r];
-    pw[(LB_K + half) * Ctot + 32 * ch + j] = dbp[ch];
+        for (int r = 0; r < 16; ++r) {
+          float* a = acc + ((r & 3) + 8 * (r >> 2) + 4 * half) * C + 32 * ch + j;
+          *a = (w ? *a : 0.f) + dw[ch][r];
+        }
+        float* b = acc + (LB_K + half) * C + 32 * ch + j;
+        *b = (w ? *b : 0.f) + dbp[ch];
+      }
+    }
+    __syncthreads();
   }
+  float* pw = partial + (int64_t)blockIdx.x * (LB_K + 2) * Ctot + c_lo;
+  for (int i = tid; i < (LB_K + 2) * C; i += 64 * LB_WAVES) pw[(i / C) * Ctot + (i % C)] = acc[i];
 }
 
 unsigned lb_grid(int64_t R) {
@@ -317,7 +335,7 @@ extern "C" int hotk_linear_bwd_supported(int64_t K, int64_t C) { return (K == LB
 
 extern "C" int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials) {
   HOTK_CHECK_ARG(n_partials && R >= 0);
-  *n_partials = (int64_t)lb_grid(R) * LB_WAVES;
+  *n_partials = (int64_t)lb_grid(R);
   return HOTK_OK;
 }
 
@@ -329,8 +347,8 @@ extern "C" int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x
   HOTK_CHECK_ARG(hotk_aligned16(g) && hotk_aligned16(x) && (!dx || hotk_aligned16(dx)) && ((ldg | ldx) & 3) == 0 &&
                  (!dx || (lddx & 3) == 0));
   if (R == 0) {
-    // the caller sums lb_grid(0) * WAVES partial blocks: give it zeros
-    return hipMemsetAsync(partial, 0, (size_t)LB_WAVES * (LB_K + 2) * C * sizeof(float), (hipStream_t)stream) == hipSuccess
+    // the caller sums lb_grid(0) = 1 partial block: give it zeros
+    return hipMemsetAsync(partial, 0, (size_t)(LB_K + 2) * C * sizeof(float), (hipStream_t)stream) == hipSuccess
                ? HOTK_OK : HOTK_ELAUNCH;
   }
   hipStream_t st = (hipStream_t)stream;

@@ -12,6 +12,7 @@ from torch.autograd import Function
 
 from . import _lib
 from ._lib import lib, p, check, call, stream_ptr, rows2d, KEEP_DIAG, KEEP_OFFDIAG, KEEP_VALID, SEG_CHUNK
+from .plan import Seg
 
 
 # ------------------------------------------------------------------------------------------------
@@ -35,50 +36,67 @@ def mask_rows(src, kind, keep, fill=0.0):
     return out
 
 
-_REFINED = {}
 SEG_SPLIT = 256        # rows one thread adds at most (<= the ABI's HOTK_SEG_CHUNK)
 POOL_SPLIT = 2048      # rows one wavefront of the softmax-pooling kernel walks at most
 
 
+class _Refined:
+    """pieces of a segment list: `fine` (the pieces, a segment list over the same positions), `group` (per original
+    segment the range of its pieces), `owner` (piece -> original segment); rows()/piece_of_row() on demand"""
+
+    def __init__(self, seg, chunk):
+        beg, end, perm, maxlen = seg
+        n_seg = beg.numel()
+        length = (end.long() - beg.long()).clamp_min(0)
+        pieces = (length + chunk - 1) // chunk
+        gend = torch.cumsum(pieces, 0)
+        gbeg = gend - pieces
+        # the two host reads of this bookkeeping (piece count, most pieces of one segment): once per plan and segment list
+        total, most = (int(v) for v in torch.stack([gend[-1], pieces.max()]).tolist()) if n_seg else (0, 0)
+        owner = torch.repeat_interleave(torch.arange(n_seg, device=beg.device), pieces, output_size=total)
+        k = torch.arange(total, device=beg.device) - gbeg[owner]
+        vbeg = beg.long()[owner] + k * chunk
+        vend = torch.minimum(vbeg + chunk, end.long()[owner])
+        i32 = lambda t: t.to(torch.int32).contiguous()
+        self.fine = (i32(vbeg), i32(vend), perm, min(int(maxlen), int(chunk)))
+        self.group = (i32(gbeg), i32(gend), None, most)
+        self.owner = i32(owner)
+        self._rows = None
+
+    def rows(self):
+        """(row ids covered by the pieces, piece after piece; the piece of each of them)"""
+        if self._rows is None:
+            fb, fe = self.fine[0], self.fine[1]
+            length = (fe - fb).long()
+            start = torch.cumsum(length, 0) - length
+            total = int(length.sum())
+            piece = torch.repeat_interleave(torch.arange(fb.numel(), device=fb.device), length, output_size=total)
+            self._rows = (fb.long()[piece] + (torch.arange(total, device=fb.device) - start[piece]), piece)
+        return self._rows
+
+
+def refined(seg, chunk=SEG_CHUNK):
+    """Segments longer than `chunk` cut into consecutive pieces of at most `chunk` positions (-> _Refined).  Summing
+    `fine` and then `group` adds every segment in a fixed order without atomics; a segment with more than SEG_CHUNK pieces
+    is refined again by the caller.  Index bookkeeping (torch ops + one host read), built once per plan for the plan's own
+    segment lists (plan.Seg) and kept on the plan; any other segment list is refined afresh on every call."""
+    plan = getattr(seg, 'plan', None)
+    if plan is None:
+        return _Refined(seg, chunk)
+    cache = plan.__dict__.setdefault('_refined', {})
+    key = (seg.name, int(chunk))
+    hit = cache.get(key)
+    if hit is None:
+        hit = cache[key] = _Refined(seg, chunk)
+        # the pieces are segment lists of the same plan: a second refinement (one graph of millions of rows) is kept too
+        hit.fine = Seg(*hit.fine, plan, f'{seg.name}/fine{chunk}')
+        hit.group = Seg(*hit.group, plan, f'{seg.name}/group{chunk}')
+    return hit
+
+
 def refine_seg(seg, chunk=SEG_CHUNK):
-    """Segments longer than `chunk` cut into consecutive pieces of at most `chunk` positions.
-    -> (fine, group): `fine` = the pieces as a segment list over the same positions (same perm), `group` = for every
-    original segment the contiguous range of its pieces (a segment list over the rows of a per-piece partial result).
-    Summing `fine` and then `group` adds every segment in a fixed order without atomics; a segment with more than
-    SEG_CHUNK pieces is refined again by the caller.  Index bookkeeping (torch ops + ONE host read of the piece count),
-    cached per segment list."""
-    beg, end, perm, maxlen = seg
-    key = (beg.data_ptr(), end.data_ptr(), beg.numel(), int(maxlen), int(chunk))
-    hit = _REFINED.get(key)
-    if hit is not None:
-        return hit[1], hit[2]
-    if len(_REFINED) > 64:
-        _REFINED.clear()
-    n_seg = beg.numel()
-    length = (end.long() - beg.long()).clamp_min(0)
-    pieces = (length + chunk - 1) // chunk
-    gend = torch.cumsum(pieces, 0)
-    gbeg = gend - pieces
-    total = int(gend[-1]) if n_seg else 0
-    owner = torch.repeat_interleave(torch.arange(n_seg, device=beg.device), pieces, output_size=total)
-    k = torch.arange(total, device=beg.device) - gbeg[owner]
-    vbeg = beg.long()[owner] + k * chunk
-    vend = torch.minimum(vbeg + chunk, end.long()[owner])
-    i32 = lambda t: t.to(torch.int32).contiguous()
-    fine = (i32(vbeg), i32(vend), perm, min(int(maxlen), int(chunk)))
-    group = (i32(gbeg), i32(gend), None, int(pieces.max()) if n_seg else 0)
-    group_owner = i32(owner)          # piece -> original segment
-    fine = fine + (group_owner,)
-    fine = fine[:4]
-    _REFINED[key] = ((beg, end), fine, group, group_owner)      # the key tensors stay alive with the entry: pointers are not reused
-    return fine, group
-
-
-def refined_owner(seg, chunk):
-    """piece -> original segment (int32) of refine_seg(seg, chunk)"""
-    refine_seg(seg, chunk)
-    beg, end, perm, maxlen = seg
-    return _REFINED[(beg.data_ptr(), end.data_ptr(), beg.numel(), int(maxlen), int(chunk))][3]
+    r = refined(seg, chunk)
+    return r.fine, r.group
 
 
 def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID, out=None):
@@ -823,8 +841,8 @@ class SoftmaxPool(Function):
                  keep, p(out), Cv, p(alpha), p(None), p(None), nb, H, d, c)
             owner = fine = group = None
         else:
-            fine, group = refine_seg(seg, POOL_SPLIT)
-            owner = refined_owner(seg, POOL_SPLIT)
+            ref = refined(seg, POOL_SPLIT)
+            fine, group, owner = ref.fine, ref.group, ref.owner
             fb, fe = fine[0], fine[1]
             npc = fb.numel()
             outp = torch.empty(npc, Cv, dtype=q.dtype, device=dev)
@@ -847,8 +865,7 @@ class SoftmaxPool(Function):
             if shard is not None:
                 shard.all_reduce_(out)
             # alpha of a row = its within-piece softmax weight x the weight of its piece
-            piece_of_row = torch.repeat_interleave(torch.arange(npc, device=dev), (fe - fb).long())
-            row_ids = _piece_rows(fb, fe)
+            row_ids, piece_of_row = ref.rows()
             alpha[row_ids] = alpha[row_ids] * wn[piece_of_row]
         ctx.save_for_backward(qs, ks, vs, alpha, out, beg, end)
         ctx.cfg = (ldq, ldk, ldv, nb, n, H, d, c, q.shape, k.shape, v.shape)
@@ -877,15 +894,6 @@ class SoftmaxPool(Function):
                  p(alpha), p(out), H * c, p(g), H * c, p(dqp), H * d, p(dk), H * d, p(dv), H * c, p(owner), npc, H, d, c)
             dq = seg_sum_rows(dqp, group)
         return dq.view(qshape), dk.view(kshape), dv.view(vshape), None, None, None, None, None
-
-
-def _piece_rows(fb, fe):
-    """row ids covered by the pieces [fb[p], fe[p]), piece after piece"""
-    length = (fe - fb).long()
-    start = torch.cumsum(length, 0) - length
-    total = int(length.sum())
-    piece = torch.repeat_interleave(torch.arange(fb.numel(), device=fb.device), length, output_size=total)
-    return fb.long()[piece] + (torch.arange(total, device=fb.device) - start[piece])
 
 
 def _ptr(t):
@@ -1273,8 +1281,10 @@ class AttnLayer22BF16(Function):
         dxd = dyn @ Wn.t()
         dx2 = (g @ W2[D:3 * D].t().to(bf)).float()
         dx = torch.empty(R, D, dtype=torch.float32, device=dev)
+        dxv32 = dxv.float()          # bound to a name: the block must stay out of the caching allocator until the launch is enqueued
         call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D,
-             p(dxv.float()), D, p(dx), D, R, D)
+             p(dxv32), D, p(dx), D, R, D)
+        del dxv32
         dWn = wgrad(xd, dyn)
         dW2 = torch.cat([dWn[:, 0:C], wgrad(x2b, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
         xshape, h1shape = ctx.shapes

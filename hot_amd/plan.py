@@ -13,6 +13,17 @@ from . import _lib
 from ._lib import lib, p, check, stream_ptr
 
 
+class Seg(tuple):
+    """A segment list (beg, end, perm, maxlen) that remembers the plan it is a view of and its name there, so that
+    derived index lists (hot_amd.ops.refine_seg) are built once per plan and kept ON the plan -- no pointer-keyed cache,
+    nothing that outlives the plan or goes stale when a buffer is reused."""
+
+    def __new__(cls, beg, end, perm, maxlen, plan=None, name=None):
+        self = super().__new__(cls, (beg, end, perm, maxlen))
+        self.plan, self.name = plan, name
+        return self
+
+
 class Plan:
     """int32 device arrays over padded rows: R = B*Emax entry rows, Nn = B*Nmax node rows."""
 
@@ -98,15 +109,15 @@ class Plan:
 
     # CSR views ---------------------------------------------------------------------------------
     def col_seg(self):
-        return self.col_ptr[:-1], self.col_ptr[1:], self.col_perm, self.max_col_deg
+        return Seg(self.col_ptr[:-1], self.col_ptr[1:], self.col_perm, self.max_col_deg, self, 'col')
 
     def row_seg(self):
-        return self.row_ptr[:-1], self.row_ptr[1:], self.row_perm, self.max_row_deg
+        return Seg(self.row_ptr[:-1], self.row_ptr[1:], self.row_perm, self.max_row_deg, self, 'row')
 
     def graph_seg(self, order):
         if order == 1:
-            return self.g_nbeg, self.g_nend, None, self.Nmax
-        return self.g_ebeg, self.g_eend, None, self.Emax
+            return Seg(self.g_nbeg, self.g_nend, None, self.Nmax, self, 'graph1')
+        return Seg(self.g_ebeg, self.g_eend, None, self.Emax, self, 'graph2')
 
     def unit_seg(self, n):
         return self.iota[:n], self.iota[1:n + 1], None, 1
@@ -135,7 +146,7 @@ class NodePlan:
 
     def graph_seg(self, order):
         assert order == 1
-        return self.g_nbeg, self.g_nend, None, self.Nmax
+        return Seg(self.g_nbeg, self.g_nend, None, self.Nmax, self, 'graph1')
 
     def unit_seg(self, n):
         return self.iota[:n], self.iota[1:n + 1], None, 1

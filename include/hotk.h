@@ -264,7 +264,7 @@ int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int6
 
 /* Backward of a narrow-input linear layer y[R, C] = x[R, K] @ W[K, C] + b in one pass over g = dy [R, C]
  * (nn.Linear fc_v of models/sparse/kernelattn.py:51,65-68 under autograd; the reference gets the three gradients from
- * aten's addmm backward):  dx[R, K] = g @ W^T;  partial[n][K + 2][C]: per-wave partial sums of x^T @ g (rows 0..K-1)
+ * aten's addmm backward):  dx[R, K] = g @ W^T;  partial[n][K + 2][C]: per-workgroup partial sums of x^T @ g (rows 0..K-1)
  * and of the column sums of g (rows K, K + 1).  The caller sums the n = hotk_linear_bwd_partials(R) blocks in order:
  * dW = sum[0:K], db = sum[K] + sum[K + 1].  dx = NULL: only the partial sums (W is not read) -- the weight gradient of a
  * wide-INPUT layer y = a @ W^T is the same product with x := dy and g := a (fc_o, kernelattn.py:52).  Shapes: K = 32 and C in {64, 320} (hotk_linear_bwd_supported), others
@@ -342,8 +342,14 @@ int hotk_attn22_backward(const hotk_attn22_args* args, void* workspace, size_t w
  * Limit: hotk_attn22_workspace_bytes(B, Emax) <= HOTK_ATTN22_STATIC_SCRATCH_BYTES, i.e. at most 3 640 row chunks
  * (C2-sized minibatches: 128 molecules need 0.6-4.7 MB); larger batches return HOTK_ETOOLARGE and launch nothing.
  * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on
- * one stream are ordered and need no clearing in between (each call rewrites every partial it reads). */
+ * one stream are ordered and need no clearing in between (each call rewrites every partial it reads; the kernels walk
+ * with a static stride, so the array holds no counters).
+ * The array's device address is looked up once per GPU (hipGetSymbolAddress: lazy module and symbol resolution, a mutex)
+ * and cached.  hotk_attn22_static_init() does that for the CURRENT device; call it once per GPU at set-up, outside any
+ * graph capture.  Without it the first hotk_attn22_forward_static call on a GPU does the lookup itself -- for the device
+ * that owns `stream` (the current device for the null stream) -- and that first call must then not be under capture. */
 #define HOTK_ATTN22_STATIC_SCRATCH_BYTES (32u << 20)
+int hotk_attn22_static_init(void);
 int hotk_attn22_forward_static(const hotk_attn22_args* args, void* stream);
 
 /* bf16-storage forms of two row primitives around the core (hotk_attn22_args.storage = HOTK_STORAGE_BF16; no reference

@@ -65,6 +65,8 @@ def _run(plan, h1, h2, v, proj, static):
 
 
 def test_forward_static_matches_workspace_form_twice():
+    from hot_amd import _lib
+    assert _lib.lib().hotk_attn22_static_init() == 0      # set-up call: resolves the array's address on this device
     big = _core_inputs(96, 10, 40, seed=11)      # 96 graphs, up to ~200 rows each
     small = _core_inputs(7, 3, 9, seed=12)       # second call: fewer, smaller graphs
     for inputs in (big, small):
@@ -76,6 +78,13 @@ def test_forward_static_matches_workspace_form_twice():
     # and once more the large one after the small one: nothing of the small call's partial sums survives
     att_ref, kvg_ref = _run(*big, static=False)
     att, kvg = _run(*big, static=True)
+    assert torch.equal(att, att_ref) and torch.equal(kvg, kvg_ref)
+    # on a side stream: the entry point takes the device (and with it the array's address) from the stream it is handed
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        att, kvg = _run(*small, static=True)
+    att_ref, kvg_ref = _run(*small, static=False)
     assert torch.equal(att, att_ref) and torch.equal(kvg, kvg_ref)
 
 
