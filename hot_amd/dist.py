@@ -8,8 +8,9 @@ Edge-shard mode (one giant graph): every rank holds ALL nodes (diagonal entries,
 off-diagonal entries in which (i,j) and (j,i) are co-located (`shard_graph`).  Node-level work is replicated; the
 only exchanges are all-reduces of the key-value summaries built from entries (per-node and per-graph
 sum phi(K) (x) [V|1] in forward, their gradients in backward) and the final parameter-gradient all-reduce.
-Replicated diagonal entries enter entry-level sums with weight 1/world (exact for power-of-two worlds) so that the
-reduced sums count them once; the caller weights replicated output rows by `ShardInfo.entry_weight` in its loss.
+Replicated diagonal entries enter entry-level sums with weight 1/world so that the reduced sums count them once
+(bit-exact for power-of-two worlds; any other world size adds one fp32 rounding of 1/world per diagonal term, ~6e-8
+relative: tests/test_gpu_edge_shard.py runs 3 ranks against the oracle at the same 1e-5 bar); the caller weights replicated output rows by `ShardInfo.entry_weight` in its loss.
 
 Every function takes the process group explicitly or uses the default one."""
 from typing import Iterable, List, Sequence, Tuple

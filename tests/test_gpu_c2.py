@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_err
+from conftest import rel_err, oracle_fp32_fp64, hold_to_fp64, err64  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda'
@@ -57,8 +57,14 @@ def test_c2_encoder_real_dims_vs_oracle():
     """Encoder(2, 0, [2]*3, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel') -- enc-small with 3
     of its 8 identical layers -- forward + backward on 128 molecules against the oracle.  The fused attention core runs
     with D = 256 (ld_h2 = 512); the readout is the segmented softmax kernel with 8 heads of width 16.
-    Criteria: outputs <= 1e-5 of the output scale; input gradients row-wise <= 2e-5 of the gradient scale on all but <=
-    0.5 % of the rows (ReLU kinks, see test_layer_vs_oracle_ba_graphs), parameter gradients <= 1e-3."""
+    Criteria, all against the oracle run in FLOAT64 with the float32 oracle's own distance beside it: outputs <= max(1e-5,
+    2 x that distance).  Gradients: this case (three stacked ReLU-feature layers at D = 256, ~1e7 pre-activations) does hit
+    ReLU kinks -- pre-activations within fp32 rounding of 0 whose gate opens on one side only; each moves one gradient row
+    by O(1e-4) -- and the float32 oracle hits them as well (measured: it is up to 1.9e-4 from float64, 0.11 % of the
+    input-gradient rows beyond 2e-5; the HIP path 3.7e-4 / 0.11 %).  Which gates flip is a property of each side's
+    rounding, so the bar is the model-wide kink level of the reference's own precision: every gradient tensor <= max(2e-5,
+    4 x G), G = the float32 oracle's largest distance from float64 over all gradient tensors (round 2: flat 1e-3), and the
+    fraction of input-gradient rows beyond 2e-5 <= twice the float32 oracle's + 0.1 % (round 2: flat 0.5 %)."""
     from oracle import hot_oracle as O
     from hot_amd import _lib
     from hot_amd.batch import sparse as bs
@@ -75,8 +81,6 @@ def test_c2_encoder_real_dims_vs_oracle():
     enc.eval()
     for lyr in list(enc.layers)[:L]:
         assert lyr.attn._fused_ok()
-    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
-          for k, v in enc.state_dict().items()}
     x = G0.values.clone().requires_grad_(True)
     _lib.timing_begin(None)
     y = enc(bs.batch_like(G0, x, skip_masking=True))
@@ -85,27 +89,31 @@ def test_c2_encoder_real_dims_vs_oracle():
     census = _lib.timing_end()
     assert census['hotk_attn22_forward'][1] == L and census['hotk_attn22_backward'][1] == L
     assert census['hotk_seg_softmax_pool_fwd'][1] == 2
-    xo = GO.values.clone().requires_grad_(True)
-    yo = O.encoder_2_0(GO.like(xo), sd, L, DH, 32, 32, 256, 4, 128, 128, 8, True)
-    (yo * R).sum().backward()
-    e_y = rel_err(y.detach().cpu(), yo.detach())
-    gx, gxo = x.grad.cpu(), xo.grad
-    row_err = (gx - gxo).abs().amax(-1) / gxo.abs().max()
-    bad = float((row_err > 2 * TOL).float().mean())
-    # a softmax is invariant to a shift of its logits, so the readout's key biases have an exactly zero gradient that
-    # both sides compute as rounding noise: errors are measured against the larger of the parameter's own gradient
-    # scale and 1e-3 of the largest gradient in the model (as tests/test_gpu_parity.py::_check_param_grads)
-    scale = max(float(sd[k].grad.abs().max()) for k, _ in enc.named_parameters())
-    worst, worst_k = 0., None
-    for k, p_ in enc.named_parameters():
-        ref = sd[k].grad
-        e = float((p_.grad.cpu() - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * scale)
-        if e > worst:
-            worst, worst_k = e, k
-    print(f'C2 real dims: out err {e_y:.2e}, grad rows off {bad:.2e}, worst parameter grad err {worst:.2e} ({worst_k})')
-    assert e_y < TOL, e_y
-    assert bad <= 5e-3, bad
-    assert worst < 1e-3, worst
+
+    def run(xo, sd, dt):
+        yo = O.encoder_2_0(GO.like(xo), sd, L, DH, 32, 32, 256, 4, 128, 128, 8, True)
+        (yo * R.to(dt)).sum().backward()
+        return yo
+    o32, o64 = oracle_fp32_fp64(run, enc.state_dict(), GO.values)
+    e_y, gap_y = hold_to_fp64('out', y, o32[0], o64[0], TOL)
+    # gradient scale of a parameter: its own largest gradient, or 1e-3 of the largest in the model (a softmax is invariant
+    # to a shift of its logits, so the readout's key biases have an exactly zero gradient that every side computes as noise)
+    scale = max(float(v.abs().max()) for v in o64[2].values())
+    params = dict(enc.named_parameters())
+    gaps = {k: err64(o32[2][k], o64[2][k], 1e-3 * scale) for k in params}
+    gaps['d input'] = err64(o32[1], o64[1])
+    G = max(gaps.values())
+    errs = {k: err64(p_.grad, o64[2][k], 1e-3 * scale) for k, p_ in params.items()}
+    errs['d input'] = err64(x.grad, o64[1])
+    s_in = float(o64[1].abs().max())
+    rows = lambda gx: float((((gx.detach().cpu().double() - o64[1]).abs().amax(-1) / s_in) > 2 * TOL).double().mean())
+    bad, bad32 = rows(x.grad), rows(o32[1])
+    worst_k = max(errs, key=errs.get)
+    print(f'C2 real dims: out err {e_y:.2e} (oracle fp32 {gap_y:.2e}); gradients: worst {errs[worst_k]:.2e} ({worst_k}), '
+          f'oracle fp32 worst {G:.2e}; input-gradient rows off {bad:.2e} (oracle fp32 {bad32:.2e})')
+    for k, e in errs.items():
+        assert e <= max(2 * TOL, 4 * G), f'{k}: {e:.2e} against the fp64 oracle; the fp32 oracle is within {G:.2e}'
+    assert bad <= 2 * bad32 + 1e-3, (bad, bad32)
 
 
 def test_training_dropout_stays_on_fused_core():

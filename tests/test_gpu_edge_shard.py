@@ -196,10 +196,14 @@ def _free_port():
     return port
 
 
-@pytest.mark.parametrize('world,fused,generalized', [(2, True, True), (2, False, True), (4, True, True), (2, False, False)])
+@pytest.mark.parametrize('world,fused,generalized', [(2, True, True), (2, False, True), (4, True, True), (2, False, False),
+                                                    (3, True, True), (3, False, False)])
 def test_edge_shard_matches_oracle_on_whole_graph(world, fused, generalized):
     """generalized = False: the softmax feature map, whose key branch subtracts ONE maximum over the whole batch
-    (common/kernel.py:112) -- MAX-all-reduced across the shards, its gradient SUM-all-reduced (ops.Phi)"""
+    (common/kernel.py:112) -- MAX-all-reduced across the shards, its gradient SUM-all-reduced (ops.Phi).
+    world = 3: replicated diagonal entries enter the entry sums with weight 1/3, which fp32 does not represent exactly --
+    the reduced sums then carry one more rounding per term (3 x fl(1/3) x = x (1 +- 2^-24)), far inside the 1e-5 bar; only
+    power-of-two worlds reproduce the unsharded sums bit for bit (hot_amd/dist.py)"""
     import torch.multiprocessing as mp
     port = _free_port()
     ctx = mp.get_context('spawn')
@@ -346,3 +350,120 @@ def test_fused_phases_padded_batch():
     assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 2e-5
     pad = (G.plan.kind == 0).view(-1)
     assert float(y1.view(-1, y1.size(-1))[pad].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# C5 at ONE RANK'S REAL SIZE (bench.py --mode edge-shard at 1 GPU: 125 000 nodes, 3.125 M undirected pairs = 6.25 M
+# directed entries + the diagonal, B = 1, ~50 entries per node).  Reached only here: the branch R >= 24 Nn that switches
+# the work tickets off (csrc/fused22.hip ws_tickets), k_graph_reduce_wide over thousands of row chunks, refinements of
+# refinements in the segment sums (one graph of 6.4 M rows).  No oracle runs at this size and the per-graph terms make
+# every output depend on the whole graph, so the checks are size-independent properties.
+# ------------------------------------------------------------------------------------------------------------------
+def _c5_shard_graph(n_nodes=125000, n_pairs=3125000, seed=4321, perm=None):
+    """the graph of bench.py::edge_shard_mode (same seed and construction); perm: relabel node v as perm[v]"""
+    g = torch.Generator(device=DEV).manual_seed(seed)
+    i = torch.randint(0, n_nodes, (int(n_pairs * 1.02),), device=DEV, generator=g)
+    j = torch.randint(0, n_nodes, (int(n_pairs * 1.02),), device=DEV, generator=g)
+    lo, hi = torch.minimum(i, j), torch.maximum(i, j)
+    key = torch.unique((lo * n_nodes + hi)[lo != hi])[:n_pairs]
+    lo, hi = key // n_nodes, key % n_nodes
+    ei = torch.stack([torch.cat([lo, hi]), torch.cat([hi, lo])])
+    nf = torch.randn(n_nodes, 16, device=DEV, generator=g)
+    ef = torch.randn(ei.size(1), 16, device=DEV, generator=g)
+    if perm is not None:
+        ei = perm[ei]
+        nf = torch.empty_like(nf).index_copy_(0, perm, nf)        # node perm[v] carries v's features
+    order = torch.argsort(ei[0] * n_nodes + ei[1])
+    return nf, ei[:, order].contiguous(), ef[order].contiguous()
+
+
+class _LoneRankOf(object):
+    """edge-shard context of rank 0 of a world of `world` ranks with no peers attached: all-reduces return the rank's own
+    partial sums.  What the kernels compute under it -- diagonal entries weighted 1 / world in every entry sum -- is the
+    same quantity on the phased fused core and on the general kernels, which is what the test compares."""
+
+    def __init__(self, world, entry_weight):
+        self.rank, self.world, self.group, self.entry_weight = 0, world, None, entry_weight
+
+    def all_reduce_(self, t):
+        return t
+
+    def all_reduce_max_(self, t):
+        return t
+
+
+def _c5_step(G, fused, shard=None, square=False):
+    from hot_amd import _lib
+    from hot_amd.batch import sparse as bs
+    layer = _layer()
+    layer.use_fused = fused
+    plan = G.plan
+    if shard is None:
+        plan.__dict__.pop('shard', None)
+    else:
+        plan.shard = shard
+    x = G.values.clone().requires_grad_(True)
+    _lib.timing_begin(None)
+    y = layer(bs.batch_like(G, x, skip_masking=True))
+    (y.values.square() if square else y.values).sum().backward()
+    census = set(_lib.timing_end())
+    plan.__dict__.pop('shard', None)
+    return y.values.detach()[0], x.grad[0].clone(), {k: p.grad.clone() for k, p in layer.named_parameters()}, census
+
+
+def test_c5_one_rank_real_shard_size():
+    from hot_amd.batch import sparse as bs
+    from hot_amd.dist import ShardInfo
+    n = 125000
+    nf, ei, ef = _c5_shard_graph(n)
+    E = ei.size(1)
+    G = bs.make_batch_concatenated(nf, ei, ef, [n], [E])
+    plan = G.plan
+    assert plan.B == 1 and plan.R == n + E and plan.R >= 24 * plan.Nn and plan.R > 6_000_000
+    # transpose map at this size: an involution on the valid rows, every entry of a symmetric graph has its partner
+    tI, tM = G.t_indices[0], G.t_mask[0]
+    assert bool(tM.all()) and bool((tI[tI] == torch.arange(plan.R, device=DEV)).all())
+    assert bool((G.indices[0][tI] == G.indices[0].flip(-1)).all())
+    # one-pass fused core, twice: every sum runs in a fixed order -> bit-identical
+    y0, gx0, gp0, c0 = _c5_step(G, True)
+    y0b, gx0b, gp0b, _ = _c5_step(G, True)
+    assert {'hotk_attn22_forward', 'hotk_attn22_backward'} <= c0
+    assert torch.equal(y0, y0b) and torch.equal(gx0, gx0b) and all(torch.equal(gp0[k], gp0b[k]) for k in gp0)
+    assert bool(torch.isfinite(y0).all()) and float(y0.abs().max()) > 0
+    # the core in phases with a one-rank shard context == the one-pass core (to rounding: the one-pass forward runs the
+    # MFMA tiles, the phases the VALU kernels; the backward arithmetic and its ReLU gates are the same code)
+    y1, gx1, gp1, c1 = _c5_step(G, True, ShardInfo(0, 1, (plan.kind != 0).to(torch.float32)))
+    assert 'hotk_attn22_phase' in c1 and 'hotk_attn22_forward' not in c1
+    assert _rel(y1, y0) < 1e-5 and _rel(gx1, gx0) < 2e-5, (_rel(y1, y0), _rel(gx1, gx0))
+    assert max(_rel(gp1[k], gp0[k]) for k in gp0) < 2e-5
+    del y1, gx1, gp1
+    # rank 0 of a world of 8 and of 3 (diagonal entries weighted 1/8, 1/3) without peers: phased fused core against the
+    # general kernels under the same context.  Both forward paths and both backward paths differ in code here, so ReLU
+    # gates within rounding of 0 may differ: gradients row-wise, as in test_fused_one_large_graph_many_chunks
+    for world in (8, 3):
+        w = torch.where(plan.kind == 1, torch.full((plan.R,), 1.0 / world, device=DEV), (plan.kind == 2).float())
+        ya, gxa, gpa, ca = _c5_step(G, True, _LoneRankOf(world, w), square=True)
+        yb, gxb, gpb, cb = _c5_step(G, False, _LoneRankOf(world, w), square=True)
+        assert 'hotk_attn22_phase' in ca and 'hotk_attn22_phase' not in cb and 'hotk_seg_outer_sum' in cb
+        assert _rel(ya, yb) < 1e-5, (world, _rel(ya, yb))
+        assert float((ya - y0).abs().max()) > 1e-3 * float(y0.abs().max())        # the weights do change the sums
+        row_err = (gxa - gxb).abs().amax(-1) / gxb.abs().max()
+        assert float((row_err > 2e-5).float().mean()) <= 2e-3, world
+        assert max(_rel(gpa[k], gpb[k]) for k in gpa) < 1e-3, world
+        del ya, gxa, gpa, yb, gxb, gpb
+    # permutation equivariance -- the defining property of the layer (README.md:9-13) -- at full size: relabel the nodes,
+    # rebuild the batch (other row order, other segments, other chunking of every sum) and compare row by row
+    perm = torch.randperm(n, device=DEV, generator=torch.Generator(device=DEV).manual_seed(7))
+    nf2, ei2, ef2 = _c5_shard_graph(n, perm=perm)
+    G2 = bs.make_batch_concatenated(nf2, ei2, ef2, [n], [E])
+    y2, gx2, gp2, _ = _c5_step(G2, True)
+    key = lambda idx: idx[:, 0] * n + idx[:, 1]
+    k1 = key(perm[G.indices[0]])                  # where row r of G lives in G2, by its relabelled (i, j)
+    k2 = key(G2.indices[0])
+    o2 = torch.argsort(k2)
+    pos = o2[torch.searchsorted(k2[o2], k1)]
+    assert bool((k2[pos] == k1).all())
+    assert _rel(y2[pos], y0) < 1e-5, _rel(y2[pos], y0)
+    row_err = (gx2[pos] - gx0).abs().amax(-1) / gx0.abs().max()
+    assert float((row_err > 2e-5).float().mean()) <= 2e-3
+    assert max(_rel(gp2[k], gp0[k]) for k in gp0) < 1e-3

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, tt, rel_err
+from conftest import load_golden, tt, rel_err, oracle_fp32_fp64, hold_to_fp64, err64  # noqa: F401
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
@@ -442,12 +442,12 @@ def _ba_case(n_graphs, seed):
 def test_layer_vs_oracle_ba_graphs(generalized, fused, dqk):
     """C1-shaped workload (BA(64,5) graphs, D = dqk = dv = 32, 4 heads) at a size the oracle runs in seconds.
 
-    Softmax features are smooth: outputs and every gradient must agree to 1e-5 / 2e-5.
-    ReLU features have a kink at 0: among the ~5e6 pre-activations of this case a handful lie within fp32
-    rounding of 0 (|pre| ~ 1e-8), where the CPU GEMM and the GPU GEMM feeding the map legitimately disagree on
-    the sign and hence on relu'(pre) in {0, 1}.  Such a flip changes the gradient of ONE row by O(1e-3) and is
-    not a parity defect (the fp64 oracle sides with either).  So for ReLU: outputs strict, gradients strict on
-    all but <= 0.2 % of the rows, parameter gradients to 1e-3.  The small golden cases pin ReLU gradients at 2e-5.
+    Outputs, the input gradient and every parameter gradient are held against the oracle run in FLOAT64 to
+    max(1e-5 | 2e-5, 2 x the oracle's own float32-vs-float64 distance) per tensor: no flat allowance.  (ReLU features
+    have a kink at 0: a pre-activation within fp32 rounding of 0 may get relu' = 0 on one side and 1 on the other, which
+    moves one gradient row by O(1e-3).  Round 2 allowed 0.2 % of the rows and 1e-3 on parameter gradients for that; measured
+    against float64 on this case neither the HIP path nor the float32 oracle has such a flip -- every tensor is within
+    7e-6 -- so the allowance is gone.  A case that does hit a kink shows it in the float32 oracle's own distance too.)
 
     dqk = 64: the head shape of the reference's other shipped configuration (regression/examples/pcqm4m-lsc/enc.sh:3:
     dim_qk = dim_v = 64, 4 heads -> head width 16, m = int(16 ln 16) = 44 features, value width 16), which runs the general
@@ -464,31 +464,20 @@ def test_layer_vs_oracle_ba_graphs(generalized, fused, dqk):
                               KernelFeatureMap(dqk // 4, generalized_attention=generalized)).to(DEV)
     assert layer.feat_dim == (16 if dqk == 32 else 44)
     layer.use_fused = fused
-    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
-          for k, v in layer.state_dict().items()}
     x = G0.values.clone().requires_grad_(True)
     y = layer(bs.batch_like(G0, x, skip_masking=True))
     R = torch.randn(y.values.shape, generator=g)
     (y.values * R.to(DEV)).sum().backward()
-    xo = GO.values.clone().requires_grad_(True)
-    yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, dqk, dqk, 4, 'default', generalized)
-    (yo.values * R).sum().backward()
-    e_y = rel_err(y.values.detach().cpu(), yo.values.detach())
-    assert e_y < TOL, e_y
-    gx, gxo = x.grad.cpu(), xo.grad
-    if not generalized:
-        e = rel_err(gx, gxo)
-        assert e < 2 * TOL, e
-        for k, p_ in layer.named_parameters():
-            e = rel_err(p_.grad.cpu(), sd[k].grad)
-            assert e < 2 * TOL, (k, e)
-    else:
-        row_err = (gx - gxo).abs().amax(-1) / gxo.abs().max()
-        bad = float((row_err > 2 * TOL).float().mean())
-        assert bad <= 2e-3, bad
-        for k, p_ in layer.named_parameters():
-            e = rel_err(p_.grad.cpu(), sd[k].grad)
-            assert e < 1e-3, (k, e)
+
+    def run(xo, sd, dt):
+        yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, dqk, dqk, 4, 'default', generalized)
+        (yo.values * R.to(dt)).sum().backward()
+        return yo.values
+    o32, o64 = oracle_fp32_fp64(run, layer.state_dict(), GO.values)
+    hold_to_fp64('out', y.values, o32[0], o64[0], TOL)
+    hold_to_fp64('d input', x.grad, o32[1], o64[1], 2 * TOL)
+    for k, p_ in layer.named_parameters():
+        hold_to_fp64(k, p_.grad, o32[2][k], o64[2][k], 2 * TOL)
 
 
 def _ragged_case():
@@ -518,7 +507,7 @@ def _ragged_case():
 
 def test_fused_layer_ragged_hub_and_directed_graphs():
     """Edge cases of the fused core against the oracle: padding rows, segments longer than a record block, missing
-    transposes (tau = 0), an edgeless graph.  Same kink-aware gradient criterion as the BA case."""
+    transposes (tau = 0), an edgeless graph.  Same criterion as the BA case: every tensor against the float64 oracle."""
     _, _, _, bs, KernelFeatureMap, ms, _ = _product()
     from oracle import hot_oracle as O
     nfs, eis, efs, g = _ragged_case()
@@ -530,22 +519,21 @@ def test_fused_layer_ragged_hub_and_directed_graphs():
     torch.manual_seed(0)
     layer = ms.KernelSelfAttn(2, 2, 32, 32, 32, 4, 'default', 0., 0., KernelFeatureMap(8, generalized_attention=True)).to(DEV)
     assert layer._fused_ok()
-    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32 and 'projection' not in k)
-          for k, v in layer.state_dict().items()}
     x = G0.values.clone().requires_grad_(True)
     y = layer(bs.batch_like(G0, x, skip_masking=True))
     R = torch.randn(y.values.shape, generator=g)
     (y.values * R.to(DEV)).sum().backward()
-    xo = GO.values.clone().requires_grad_(True)
-    yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, 32, 32, 4, 'default', True)
-    (yo.values * R).sum().backward()
-    assert rel_err(y.values.detach().cpu(), yo.values.detach()) < TOL
+
+    def run(xo, sd, dt):
+        yo = O.kernel_self_attn(GO.like(xo), sd, 2, 2, 32, 32, 32, 4, 'default', True)
+        (yo.values * R.to(dt)).sum().backward()
+        return yo.values
+    o32, o64 = oracle_fp32_fp64(run, layer.state_dict(), GO.values)
+    hold_to_fp64('out', y.values, o32[0], o64[0], TOL)
     assert float(y.values.detach()[~G0.mask].abs().max()) == 0.0          # padding rows are exact zeros
-    gx, gxo = x.grad.cpu(), xo.grad
-    row_err = (gx - gxo).abs().amax(-1) / gxo.abs().max()
-    assert float((row_err > 2 * TOL).float().mean()) <= 5e-3
+    hold_to_fp64('d input', x.grad, o32[1], o64[1], 2 * TOL)
     for k, p_ in layer.named_parameters():
-        assert rel_err(p_.grad.cpu(), sd[k].grad) < 1e-3, k
+        hold_to_fp64(k, p_.grad, o32[2][k], o64[2][k], 2 * TOL)
 
 
 def test_full_size_replication_property():
