@@ -28,6 +28,7 @@ _SIGNATURES = {
     'hotk_gather_rows': [_P, _L, _P, _P, _L, _L, _L, _I, _P],
     'hotk_mask_rows': [_P, _L, _P, _U, _F, _P, _L, _L, _L, _P],
     'hotk_seg_sum_rows': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],
+    'hotk_seg_sum_rows_pair': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _U, _P, _P, _L, _L, _L, _L, _P],
     'hotk_bias_mask_rows': [_P, _L, _P, _P, _P, _L, _L, _P],
     'hotk_bias_grad_workspace_bytes': [_L, _L, ctypes.POINTER(_S)],
     'hotk_bias_grad_rows': [_P, _L, _P, _P, _P, _L, _L, _P, _S, _P],

@@ -127,6 +127,76 @@ __global__ void k_seg_sum_rows(const float* __restrict__ src, int64_t ld_src, co
   }
 }
 
+// ------------------------------------------------------------------ two segment sums of the same rows in one pass
+// out_a[s] / out_b[s] = sum of the kept rows of segment s of list A / list B (the row and the column CSR of a plan: every
+// entry row sits in exactly one segment of each list).  As two launches of k_seg_sum_rows the source crossed HBM twice --
+// the second launch starts after the first has streamed the whole tensor through the 256 MB last-level cache, so nothing
+// of it is left.  Here the thread of (node s, column vector) walks segment s of A and then segment s of B: the two reads of
+// a row are made by the threads of two nodes of the SAME graph, a few workgroups and a few microseconds apart, and the
+// second one is served from the last-level cache (the rows in flight over the whole chip are ~100 MB).  Same walk, same
+// fixed order per segment: bitwise the results of the two separate calls.
+template <int V>
+__device__ __forceinline__ typename VecT<V>::type seg_walk(const float* __restrict__ src, int64_t ld_src, int64_t lo, int64_t hi,
+                                                          const int32_t* __restrict__ perm, const uint8_t* __restrict__ kind,
+                                                          unsigned keep, int64_t col) {
+  using T = typename VecT<V>::type;
+  T acc = vzero(T());
+  for (int64_t p = lo; p < hi; p += SU) {
+    int64_t r[SU];
+    T v[SU];
+    int pr[SU], kk[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int64_t pp = p + u < hi ? p + u : hi - 1;
+      pr[u] = perm[pp];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      vtouch(pr[u]);
+      r[u] = (int64_t)pr[u];
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) kk[u] = (int)kind[r[u]];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) v[u] = *reinterpret_cast<const T*>(src + r[u] * ld_src + col);
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      vtouch(kk[u]);
+      vtouch(v[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u)
+      if ((p + u < hi) && hotk_keep(keep, (uint8_t)kk[u])) acc = vadd(acc, v[u]);
+  }
+  return acc;
+}
+
+template <int V>
+__global__ void k_seg_sum_rows_pair(const float* __restrict__ src, int64_t ld_src, const int32_t* __restrict__ a_begin,
+                                    const int32_t* __restrict__ a_end, const int32_t* __restrict__ a_perm,
+                                    const int32_t* __restrict__ b_begin, const int32_t* __restrict__ b_end,
+                                    const int32_t* __restrict__ b_perm, const uint8_t* __restrict__ kind, unsigned keep,
+                                    float* __restrict__ out_a, float* __restrict__ out_b, int64_t ld_out, int64_t n_seg,
+                                    uint32_t CV) {
+  using T = typename VecT<V>::type;
+  const int64_t total = n_seg * CV;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    int64_t s, cv;
+    if (total <= 0xffffffffll) {
+      const uint32_t su = (uint32_t)t / CV;
+      s = su;
+      cv = (uint32_t)t - su * CV;
+    } else {
+      s = t / CV;
+      cv = t - s * CV;
+    }
+    const T va = seg_walk<V>(src, ld_src, a_begin[s], a_end[s], a_perm, kind, keep, cv * V);
+    *reinterpret_cast<T*>(out_a + s * ld_out + cv * V) = va;
+    const T vb = seg_walk<V>(src, ld_src, b_begin[s], b_end[s], b_perm, kind, keep, cv * V);
+    *reinterpret_cast<T*>(out_b + s * ld_out + cv * V) = vb;
+  }
+}
+
 // ------------------------------------------------------------------ bias + mask (in place)
 template <int V>
 __global__ void k_bias_mask_rows(float* __restrict__ y, int64_t ld, const uint8_t* __restrict__ kind,
@@ -469,6 +539,27 @@ extern "C" int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t
   if (v4) HOTK_SEGSUM_PK(4); else HOTK_SEGSUM_PK(1);
 #undef HOTK_SEGSUM_PK
 #undef HOTK_SEGSUM_LAUNCH
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_seg_sum_rows_pair(const float* src, int64_t ld_src, const int32_t* a_begin, const int32_t* a_end,
+                                      const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end,
+                                      const int32_t* b_perm, const uint8_t* kind, unsigned keep, float* out_a, float* out_b,
+                                      int64_t ld_out, int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream) {
+  HOTK_CHECK_ARG(n_seg >= 0 && C >= 0 && ld_src >= C && ld_out >= C && max_seg_len >= 0);
+  if (n_seg == 0 || C == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(src && out_a && out_b && a_begin && a_end && a_perm && b_begin && b_end && b_perm && kind);
+  if (max_seg_len > HOTK_SEG_CHUNK) return HOTK_EUNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const bool v4 = vec4_ok(C, {ld_src, ld_out}, {src, out_a, out_b});
+  const int64_t CV = v4 ? C / 4 : C;
+  const dim3 grid(hotk_grid(n_seg * CV, 256)), block(256);
+  if (v4)
+    hipLaunchKernelGGL(k_seg_sum_rows_pair<4>, grid, block, 0, st, src, ld_src, a_begin, a_end, a_perm, b_begin, b_end, b_perm,
+                       kind, keep, out_a, out_b, ld_out, n_seg, (uint32_t)CV);
+  else
+    hipLaunchKernelGGL(k_seg_sum_rows_pair<1>, grid, block, 0, st, src, ld_src, a_begin, a_end, a_perm, b_begin, b_end, b_perm,
+                       kind, keep, out_a, out_b, ld_out, n_seg, (uint32_t)CV);
   return hotk_launch_status();
 }
 

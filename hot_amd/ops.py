@@ -119,6 +119,27 @@ def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID, out=None):
     return out
 
 
+_SEG_PAIR = os.environ.get('HOTK_SEG_PAIR', '1') == '1'
+
+
+def seg_sum_rows_pair(src, seg_a, seg_b, kind, keep, out_a, out_b):
+    """out_a / out_b = seg_sum_rows(src, seg_a / seg_b, kind, keep), the source read from HBM once (hotk_seg_sum_rows_pair);
+    lists with long segments, or without a row map, take the two separate calls"""
+    (ab, ae, ap, am), (bb, be, bp, bm) = seg_a, seg_b
+    s, ld, n, C = rows2d(src)
+    oa, lda, na, Ca = rows2d(out_a)
+    ob, ldb, nb, Cb = rows2d(out_b)
+    ok = (_SEG_PAIR and max(am, bm) <= SEG_SPLIT and ap is not None and bp is not None and kind is not None
+          and ab.numel() == bb.numel() == na == nb and lda == ldb and Ca == Cb == C
+          and oa.data_ptr() == out_a.data_ptr() and ob.data_ptr() == out_b.data_ptr())
+    if not ok:
+        seg_sum_rows(src, seg_a, kind, keep, out=out_a)
+        seg_sum_rows(src, seg_b, kind, keep, out=out_b)
+        return
+    call('hotk_seg_sum_rows_pair', 4 * C * (n + 2 * na), p(s), ld, p(ab), p(ae), p(ap), p(bb), p(be), p(bp), p(kind), keep,
+         p(oa), p(ob), lda, na, C, max(am, bm))
+
+
 def bias_grads(g, kind, want_off, want_diag):
     """(db_off, db_diag) = column sums of g over the off-diagonal / diagonal rows (hotk_bias_grad_rows: two passes,
     bitwise reproducible)"""
@@ -541,12 +562,15 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
     dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
     call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-    seg_sum_rows(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
-    seg_sum_rows(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
+    seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
     # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
-    # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows
-    db_diag = dyn[:, 0:C].sum(0) if has_b[1] else None
-    db_off = dyn[:, C:2 * C].sum(0) if has_b[0] else None
+    # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows -- and
+    # those column sums are one more row of the node-level weight gradient: [xd | 1]^T . dyn (no pass of their own)
+    db_diag = db_off = None
+    ones_row = want_dw and (has_b[0] or has_b[1])
+    if not ones_row:
+        db_diag = dyn[:, 0:C].sum(0) if has_b[1] else None
+        db_off = dyn[:, C:2 * C].sum(0) if has_b[0] else None
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
     dx = dW = None
     if want_dx:
@@ -560,7 +584,13 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
     if want_dw:
-        dWn = wgrad(xd, dyn)
+        if ones_row:
+            dWn = wgrad(torch.cat([xd, torch.ones(xd.size(0), 1, dtype=xd.dtype, device=dev)], dim=1), dyn)
+            db_diag = dWn[D, 0:C] if has_b[1] else None
+            db_off = dWn[D, C:2 * C] if has_b[0] else None
+            dWn = dWn[:D]
+        else:
+            dWn = wgrad(xd, dyn)
         dW = torch.cat([dWn[:, 0:C], wgrad(x2, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
     return dx, dW, db_off, db_diag
 
@@ -605,9 +635,12 @@ class Proj22(Function):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
         h2, xd, x2 = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
-        h1 = xd @ W1
-        call('hotk_bias_mask_rows', 8 * plan.Nn * h1.size(1), p(h1), h1.size(1), p(plan.nkind), p(None), p(b1), plan.Nn,
-             h1.size(1))
+        if b1 is not None and not nodes_padded:
+            h1 = torch.addmm(b1, xd, W1)      # no padding node rows: the bias rides on the GEMM, nothing to mask
+        else:
+            h1 = xd @ W1
+            call('hotk_bias_mask_rows', 8 * plan.Nn * h1.size(1), p(h1), h1.size(1), p(plan.nkind), p(None), p(b1), plan.Nn,
+                 h1.size(1))
         xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
         wv = Wv.t()
         v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else torch.addmm(bv, xc, wv)
@@ -668,8 +701,7 @@ class Assemble12(Function):
             g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
         dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=g.device)
         call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-        seg_sum_rows(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
-        seg_sum_rows(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
+        seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
         db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
         db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
         return dyn, db_off, db_diag, None

@@ -89,6 +89,15 @@ int hotk_mask_rows(const float* src, int64_t ld_src, const uint8_t* kind, unsign
 int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t* seg_begin, const int32_t* seg_end,
                       const int32_t* perm, const uint8_t* kind, unsigned keep, float* out, int64_t ld_out,
                       int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream);
+/* Two segment sums of the SAME source in one pass: out_a[s] / out_b[s] = the hotk_seg_sum_rows result for segment s of
+ * list A / list B (both with a position -> row map and the kind filter), bit for bit.  For the row and column CSR of one
+ * plan -- the two node gradients of Linear(2, 2, 'light'), models/sparse/linear.py:157-159 under autograd (scatter_add_
+ * of the two gathers) -- every source row is then fetched from HBM once and the second time from the last-level cache,
+ * instead of crossing HBM in two launches.  n_seg segments in both lists, out_a / out_b share ld_out. */
+int hotk_seg_sum_rows_pair(const float* src, int64_t ld_src, const int32_t* a_begin, const int32_t* a_end,
+                           const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end, const int32_t* b_perm,
+                           const uint8_t* kind, unsigned keep, float* out_a, float* out_b, int64_t ld_out, int64_t n_seg,
+                           int64_t C, int64_t max_seg_len, void* stream);
 /* y[r] = kind 2: y + b_off, kind 1: y + b_diag, kind 0: 0   (in place).  order-2 _Bias + apply_mask
  * (models/sparse/linear.py:297-306,345-346); order 1: pass nkind and b_diag (b_off may be NULL). */
 int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* b_off, const float* b_diag,

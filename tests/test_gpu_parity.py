@@ -900,3 +900,31 @@ def test_relu_feature_map_every_dispatch_path(HH, d, m):
     safe = (np.abs(pre) > 1e-5).all(axis=(1, 2))
     dx = xd.grad.cpu()
     assert rel_err(dx[torch.from_numpy(safe)], torch.from_numpy(dref[safe]).float()) < TOL
+
+
+def test_seg_sum_rows_pair_is_the_two_calls_bit_for_bit():
+    """hotk_seg_sum_rows_pair (row and column sums of the same rows in one pass, the node gradients of Linear(2,2,'light'))
+    against two hotk_seg_sum_rows calls: same walk, same order -> identical bits; ragged graphs (padding rows, a hub, missing
+    transposes) and BA graphs, a width that takes the float4 path and one that does not, destination = column slices."""
+    _lib, ops, _, bs, *_ = _product()
+    for case in (_ragged_case(), _ba_case(12, 5)):
+        nfs, eis, efs, g = case
+        G0 = bs.make_batch([x.to(DEV) for x in nfs], [x.to(DEV) for x in eis], [x.to(DEV) for x in efs])
+        plan = G0.plan
+        for C in (288, 30):
+            src = torch.randn(plan.R, C, generator=g).to(DEV)
+            ref = torch.full((plan.Nn, 3 * C), 7.0, device=DEV)
+            ops.seg_sum_rows(src, plan.row_seg(), plan.kind, _lib.KEEP_OFFDIAG, out=ref[:, C:2 * C])
+            ops.seg_sum_rows(src, plan.col_seg(), plan.kind, _lib.KEEP_OFFDIAG, out=ref[:, 2 * C:])
+            out = torch.full((plan.Nn, 3 * C), 7.0, device=DEV)
+            _lib.timing_begin(None)
+            ops.seg_sum_rows_pair(src, plan.row_seg(), plan.col_seg(), plan.kind, _lib.KEEP_OFFDIAG, out[:, C:2 * C], out[:, 2 * C:])
+            ran = _lib.timing_end()
+            assert ('hotk_seg_sum_rows_pair' in ran) == (max(plan.max_row_deg, plan.max_col_deg) <= ops.SEG_SPLIT)
+            assert torch.equal(out, ref)
+            # and against an fp64 sum over the index lists
+            idx, kind = G0.indices.view(-1, 2), plan.kind
+            off = (kind == 2)
+            want = torch.zeros(plan.Nn, C, dtype=torch.float64, device=DEV)
+            want.index_add_(0, plan.rown[off].long(), src[off].double())
+            assert rel_err(out[:, C:2 * C].cpu(), want.cpu()) < TOL
