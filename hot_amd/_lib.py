@@ -88,6 +88,10 @@ _SIGNATURES.update({
     'hotk_attn22_phase': [ctypes.POINTER(Attn22Args), c_int, _P, _S, _P],
     'hotk_attn22_forward_static': [ctypes.POINTER(Attn22Args), _P],
     'hotk_attn22_static_init': [],
+    'hotk_layernorm_fwd': [_P, _L, _P, _P, _P, _U, ctypes.c_float, _P, _L, _P, _L, _L, _P],
+    'hotk_layernorm_bwd': [_P, _L, _P, _L, _P, _P, _P, _U, _P, _L, _P, _L, _L, _P],
+    'hotk_layernorm_partials': [_L, ctypes.POINTER(_L)],
+    'hotk_layernorm_supported': [_L],
     'hotk_linear22_entry_fwd_bf16': [_P, _L, _P, _L, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_assemble22_bf16': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_seg_sum_rows_bf16': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],

@@ -5,7 +5,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ...batch.sparse import Batch as B, apply, add_batch
+from ...batch.sparse import Batch as B, apply, add_batch, batch_like
+from ... import ops
 
 
 class Apply(nn.Module):
@@ -15,6 +16,13 @@ class Apply(nn.Module):
         self.skip_masking = skip_masking
 
     def forward(self, G: Union[torch.Tensor, B]) -> Union[torch.Tensor, B]:
+        if isinstance(self.f, nn.LayerNorm) and isinstance(G, B) and ops.layernorm_ok(G.values, self.f):
+            # LayerNorm and the zeroing of the padding rows in one HIP kernel (encoder.py:36,40-41: Apply(LayerNorm))
+            kind = None
+            if not self.skip_masking and G._padded:
+                kind = G.plan.kind if G.order == 2 else G.plan.nkind
+            y = ops.LayerNormRows.apply(G.values, self.f.weight, self.f.bias, kind, self.f.eps)
+            return batch_like(G, y, skip_masking=True)
         return apply(G, self.f, self.skip_masking)
 
 

@@ -295,6 +295,44 @@ def thin_gemm_bf16(A, W, bias=None):
 # ------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------
+class LayerNormRows(Function):
+    """y = LayerNorm(x) over the last dimension with the padding rows zeroed in the same pass (kind None: every row is
+    normalised).  Stands in for Apply(nn.LayerNorm) + batch_like's masking clone (models/encoder.py:36,40-41,
+    sparse/f.py:20-27): one kernel forward, one backward (csrc/norm.hip) instead of aten's layer norm + a mask copy and
+    three backward kernels + the mask's."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, kind, eps):
+        xs, ld, n, D = rows2d(x)
+        y = torch.empty(n, D, dtype=x.dtype, device=x.device)
+        stats = torch.empty(n, 2, dtype=torch.float32, device=x.device)
+        call('hotk_layernorm_fwd', 8 * n * D, p(xs), ld, p(gamma), p(beta), p(kind), KEEP_VALID, c_float(eps), p(y), D, p(stats),
+             n, D)
+        ctx.save_for_backward(xs, stats, gamma, kind)
+        ctx.cfg = (ld, n, D, x.shape)
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        xs, stats, gamma, kind = ctx.saved_tensors
+        ld, n, D, shape = ctx.cfg
+        gs, ldg, ng, Dg = rows2d(g.contiguous())
+        dx = torch.empty(n, D, dtype=g.dtype, device=g.device)
+        npart = ctypes_long()
+        check(lib().hotk_layernorm_partials(n, byref(npart)), 'hotk_layernorm_partials')
+        part = torch.empty(npart.value, 2, D, dtype=torch.float32, device=g.device)
+        call('hotk_layernorm_bwd', 12 * n * D, p(gs), ldg, p(xs), ld, p(stats), p(gamma), p(kind), KEEP_VALID, p(dx), D, p(part),
+             n, D)
+        tot = part.sum(0)
+        return dx.view(shape), tot[0], tot[1], None, None
+
+
+def layernorm_ok(x, ln):
+    return (x.is_cuda and x.dtype == torch.float32 and ln.elementwise_affine and ln.bias is not None
+            and len(ln.normalized_shape) == 1 and lib().hotk_layernorm_supported(int(x.size(-1))) == 1
+            and x.size(-1) == ln.normalized_shape[0])
+
+
 class GatherRows(Function):
     """out[r] = src[idx[r]] (zeros where idx < 0); idx_bwd is the inverse map (the maps used on this path
     are injective: transpose positions, diagonal positions).

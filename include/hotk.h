@@ -283,6 +283,20 @@ int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);
 int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K, int64_t C,
                           float* dx, int64_t lddx, float* partial, int64_t R, void* stream);
 
+/* LayerNorm over the rows of a batch with the padding mask folded in: y[r] = (keep >> kind[r]) & 1 ? LN(x[r]) * gamma +
+ * beta : 0 (kind NULL: every row), stats[r] = {mean, rstd} for the backward.  replaces Apply(nn.LayerNorm) + batch_like's
+ * masked_fill clone in EncLayer (models/encoder.py:36,40-41, sparse/f.py:20-27, utils/set.py:47-48) and, in _bwd, aten's
+ * three layer-norm backward kernels plus the mask's: dx (zero on rows not kept) and per-workgroup partial sums
+ * partial[n][2][D] of dgamma | dbeta, n = hotk_layernorm_partials(R), summed by the caller in order.  biased variance,
+ * eps inside the root (torch.nn.LayerNorm).  D % 4 == 0, D <= 1024 (hotk_layernorm_supported), rows 16-byte aligned. */
+int hotk_layernorm_supported(int64_t D);
+int hotk_layernorm_partials(int64_t R, int64_t* n_partials);
+int hotk_layernorm_fwd(const float* x, int64_t ld_x, const float* gamma, const float* beta, const uint8_t* kind,
+                       unsigned keep, float eps, float* y, int64_t ld_y, float* stats, int64_t R, int64_t D, void* stream);
+int hotk_layernorm_bwd(const float* g, int64_t ld_g, const float* x, int64_t ld_x, const float* stats, const float* gamma,
+                       const uint8_t* kind, unsigned keep, float* dx, int64_t ld_dx, float* partial, int64_t R, int64_t D,
+                       void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused attention core of KernelSelfAttn(2,2) (models/sparse/kernelattn.py:119-159): all ten kernel-attention
  * terms from the raw projections, for the shape 4 heads x 16 features (one wavefront per slot), head width 8,

@@ -928,3 +928,40 @@ def test_seg_sum_rows_pair_is_the_two_calls_bit_for_bit():
             want = torch.zeros(plan.Nn, C, dtype=torch.float64, device=DEV)
             want.index_add_(0, plan.rown[off].long(), src[off].double())
             assert rel_err(out[:, C:2 * C].cpu(), want.cpu()) < TOL
+
+
+@pytest.mark.parametrize('D', [32, 100, 256, 512, 1024])
+def test_layernorm_rows_with_mask_vs_fp64(D):
+    """hotk_layernorm_fwd / _bwd (csrc/norm.hip): Apply(nn.LayerNorm) of EncLayer with the padding mask folded in
+    (encoder.py:36,40-41 + batch_like's masked_fill), against torch's layer norm in float64 followed by the mask; outputs
+    and the three gradients, ragged batch (padding rows hold garbage on purpose), order 2 and order 1, and the unmasked form."""
+    _lib, ops, _, bs, *_ = _product()
+    from hot_amd.models.sparse.f import Apply
+    nfs, eis, efs, g = _ragged_case()
+    G0 = bs.make_batch([x.to(DEV) for x in nfs], [x.to(DEV) for x in eis], [x.to(DEV) for x in efs])
+    torch.manual_seed(D)
+    ln = torch.nn.LayerNorm(D).to(DEV)
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.3)
+        ln.bias.normal_(0.0, 0.3)
+    for G in (G0, bs.d(G0)):
+        vals = (torch.randn(*G.values.shape[:-1], D, generator=g) * 2 + 0.5).to(DEV)      # padding rows too
+        for skip in (False, True):
+            x = vals.clone().requires_grad_(True)
+            ln.zero_grad()
+            _lib.timing_begin(None)
+            H = Apply(ln, skip_masking=skip)(bs.batch_like(G, x, skip_masking=True))
+            W = torch.randn(H.values.shape, generator=g).to(DEV)
+            (H.values * W).sum().backward()
+            assert 'hotk_layernorm_fwd' in _lib.timing_end()
+            xd = vals.double().requires_grad_(True)
+            wd, bd = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+            yd = torch.nn.functional.layer_norm(xd, (D,), wd, bd, ln.eps)
+            if not skip:
+                yd = yd * G.mask.unsqueeze(-1)
+            (yd * W.double()).sum().backward()
+            assert rel_err(H.values.detach().cpu(), yd.detach().cpu()) < TOL
+            if not skip:
+                assert float(H.values.detach()[~G.mask].abs().max()) == 0.0 and float(x.grad[~G.mask].abs().max()) == 0.0
+            assert rel_err(x.grad.cpu(), xd.grad.cpu()) < 2 * TOL
+            assert rel_err(ln.weight.grad.cpu(), wd.grad.cpu()) < 2 * TOL and rel_err(ln.bias.grad.cpu(), bd.grad.cpu()) < 2 * TOL
