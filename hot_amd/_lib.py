@@ -92,6 +92,12 @@ _SIGNATURES.update({
     'hotk_layernorm_bwd': [_P, _L, _P, _L, _P, _P, _P, _U, _P, _L, _P, _L, _L, _P],
     'hotk_layernorm_partials': [_L, ctypes.POINTER(_L)],
     'hotk_layernorm_supported': [_L],
+    'hotk_gemm6_nn_supported': [_L, _L, _L],
+    'hotk_gemm6_tn_supported': [_L, _L, _L],
+    'hotk_gemm6_split_weight': [_P, _L, _L, _L, c_int, _P, _P],
+    'hotk_gemm6_nn': [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P],
+    'hotk_gemm6_tn_partials': [_L, _L, _L, ctypes.POINTER(_L)],
+    'hotk_gemm6_tn': [_P, _L, _P, _L, _P, _L, _L, _L, _P],
     'hotk_linear22_entry_fwd_bf16': [_P, _L, _P, _L, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_assemble22_bf16': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_seg_sum_rows_bf16': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],

@@ -1,0 +1,546 @@
+// fp32-exact tiled GEMMs on the bf16 matrix pipe, for the dense projections that are too wide for the LDS-resident
+// thin GEMM (csrc/gemm.hip): C2's hidden width 256 / 512 and the dqk = 64 head shape, where the projections ARE
+// GEMM-shaped and MFMA-bound (5.2 MFLOP per entry at C2) and the library's fp32 kernels run at the fp32 matrix
+// rate (v_mfma_f32_32x32x2_f32: 256 FLOP/clk/CU).  An fp32 number is exactly the sum of three bf16 numbers (hi / mid /
+// lo, see csrc/gemm.hip), so a product is nine bf16 products, of which the six of relative weight >= 2^-16 are summed in
+// the fp32 accumulator of v_mfma_f32_32x32x16_bf16: 6 x 32 cycles per 16 k against 8 x 64 for the fp32 MFMA, 1.8e-7
+// relative against fp64 (the library's fp32 GEMM: 2.1e-7).
+//
+//   hotk_gemm6_nn :  C[M, N]      = A[M, K] . B (+ bias)       rows M ~ 1e5..1e7; B = weight, pre-split once per call into
+//                                                              bf16 planes [3][N][K] by hotk_gemm6_split_weight
+//   hotk_gemm6_tn :  P[S][K][N]   = A[M_s, K]^T . G[M_s, N]    weight gradients: the row dimension is cut into S slabs, one
+//                                                              partial product per slab, summed by the caller in order
+// Reference: the aten addmm / mm calls under nn.Linear and _Weight.get_output (models/sparse/linear.py:46-48,
+// kernelattn.py:65-72) and their autograd.
+//
+// Tile: 256 x 256 per workgroup of 8 waves (2 x 4, a wave owns 128 x 64 = eight 32 x 32 MFMA tiles, 128 accumulator
+// registers), k step 32.  Operands of a step sit in LDS as three bf16 planes [plane][row or column][32 k], 80-byte rows
+// (16 lanes x 16 B hit 64 distinct banks), a lane's MFMA fragment = one ds_read_b128.  The next step's global loads are
+// issued into registers before the current step's products and written to LDS after them (one LDS buffer of 120 KB, one
+// workgroup per CU).  Why this tile: with 128 x 128 tiles (two workgroups per CU) the kernel was bound by L2 -> CU traffic,
+// not by the matrix pipe -- every workgroup pulls 16 KB of A and 24 KB of B planes per k step, 5.1 GB per [254 k, 512] x
+// [512, 512] product, and a build with the products compiled out still took 0.94 of its 1.14 ms; a 256 x 256 tile moves half
+// the bytes per product.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t g6_f2u(float f) { return __builtin_bit_cast(uint32_t, f); }
+__device__ __forceinline__ float g6_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
+// the three bf16 planes of two values, packed (low half = x0)
+__device__ __forceinline__ void g6_split_pair(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+  const uint32_t h0 = g6_f2u(x0) & 0xffff0000u, h1 = g6_f2u(x1) & 0xffff0000u;
+  const float r0 = x0 - g6_u2f(h0), r1 = x1 - g6_u2f(h1);
+  const uint32_t m0 = g6_f2u(r0) & 0xffff0000u, m1 = g6_f2u(r1) & 0xffff0000u;
+  const float s0 = r0 - g6_u2f(m0), s1 = r1 - g6_u2f(m1);
+  hi = (h0 >> 16) | h1;
+  mid = (m0 >> 16) | m1;
+  lo = (g6_f2u(s0) >> 16) | (g6_f2u(s1) & 0xffff0000u);
+}
+__device__ __forceinline__ f32x16 g6_mfma(const u32x4& a, const u32x4& b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+struct Frag { u32x4 h, m, l; };
+// acc += A . B with both operands as three planes; the three products below 2^-24 of the result are dropped, the small
+// terms are added first
+__device__ __forceinline__ f32x16 g6_mfma6(const Frag& a, const Frag& b, f32x16 c) {
+  c = g6_mfma(a.l, b.h, c);
+  c = g6_mfma(a.h, b.l, c);
+  c = g6_mfma(a.m, b.m, c);
+  c = g6_mfma(a.m, b.h, c);
+  c = g6_mfma(a.h, b.m, c);
+  c = g6_mfma(a.h, b.h, c);
+  return c;
+}
+
+// ---- loads the compiler does not count ------------------------------------------------------------------------------
+// With more than one k step in flight in registers (HOTK_G6_DEPTH > 1), hipcc's wait-count pass cannot follow the register
+// ring across the loop's back edge and puts s_waitcnt vmcnt(0) at the loop header.  So the ring's loads are issued by
+// inline asm -- which the compiler treats as complete -- and waited for by hand: vmcnt counts in order, the oldest set is
+// complete once at most the loads of the younger sets are outstanding.  g6_arrived() makes the registers "defined" only
+// after that wait, so no use can move above it; g6_drain() runs after the loop, before any register of the ring is reused.
+__device__ __forceinline__ void g6_ld16(u32x4& dst, const void* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(dst) : "v"(p) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void g6_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
+}
+__device__ __forceinline__ void g6_arrived(u32x4& v) { asm volatile("" : "+v"(v) : : "memory"); }
+__device__ __forceinline__ void g6_drain() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
+
+// timing probes (A/B builds only; results are wrong with either): NOLOAD re-reads the first k step (cache hits: no memory
+// time), NOPROD skips the products of all but the first k step (data movement, splits and barriers only)
+#ifdef HOTK_G6_NOLOAD
+#define HOTK_G6_PROBE_KSEL(k) 0
+#else
+#define HOTK_G6_PROBE_KSEL(k) (k)
+#endif
+#ifdef HOTK_G6_NOPROD
+#define HOTK_G6_PROBE_PROD(c, first) ((c) && (first))
+#else
+#define HOTK_G6_PROBE_PROD(c, first) (c)
+#endif
+
+#ifndef HOTK_G6_BM
+#define HOTK_G6_BM 256
+#endif
+#ifndef HOTK_G6_BN
+#define HOTK_G6_BN 256
+#endif
+#ifndef HOTK_G6_WM
+#define HOTK_G6_WM 2
+#endif
+#ifndef HOTK_G6_WN
+#define HOTK_G6_WN 4
+#endif
+#ifndef HOTK_G6_DEPTH
+#define HOTK_G6_DEPTH 1
+#endif
+#ifndef HOTK_G6_WGS
+#define HOTK_G6_WGS 1      /* workgroups per CU the register budget is set for */
+#endif
+constexpr int BM = HOTK_G6_BM, BN = HOTK_G6_BN, BK = 32, DEPTH = HOTK_G6_DEPTH;
+constexpr int WM = HOTK_G6_WM, WN = HOTK_G6_WN, TM = BM / (32 * WM), TN = BN / (32 * WN);
+static_assert(WM * TM * 32 == BM && WN * TN * 32 == BN, "the waves tile the block");
+constexpr int G6_THREADS = 64 * WM * WN;
+constexpr int ROWB = 80;                       // bytes per LDS row of a plane: 32 bf16 + 16 B padding
+constexpr int PLANE_A = BM * ROWB, PLANE_B = BN * ROWB;
+constexpr int OPER_A = 3 * PLANE_A, OPER_B = 3 * PLANE_B;
+constexpr int AP = BM * 4 / G6_THREADS, BP = BN * 4 / G6_THREADS;   // 8-element pieces (row, quarter of the 32 k) per thread
+static_assert(AP * G6_THREADS == BM * 4 && BP * G6_THREADS == BN * 4, "pieces divide over the threads");
+
+// fragments of one k16 step s for NB 32-row (or 32-column) blocks of the wave starting at `base`
+template <int NB>
+__device__ __forceinline__ void g6_frags(const unsigned char* oper, int plane, int base, int s, int lane, Frag (&f)[NB]) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const unsigned char* p = oper + (base + 32 * i + r) * ROWB + (16 * s + 8 * h) * 2;
+    f[i].h = *reinterpret_cast<const u32x4*>(p);
+    f[i].m = *reinterpret_cast<const u32x4*>(p + plane);
+    f[i].l = *reinterpret_cast<const u32x4*>(p + 2 * plane);
+  }
+}
+
+// the products of a k step: each of the six plane pairs over the wave's tiles, so that independent accumulators separate
+// two MFMAs of one chain (a dependent 32x32x16 MFMA issues only after the previous one's 8 passes)
+__device__ __forceinline__ void g6_products(const unsigned char* lds_a, const unsigned char* lds_b, int wm, int wn, int lane,
+                                            f32x16 (&acc)[TM][TN]) {
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    Frag fa[TM], fb[TN];
+    g6_frags<TM>(lds_a, PLANE_A, 32 * TM * wm, s, lane, fa);
+    g6_frags<TN>(lds_b, PLANE_B, 32 * TN * wn, s, lane, fb);
+#define HOTK_G6_STEP(PA, PB)                                                     \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = g6_mfma(fa[i].PA, fb[j].PB, acc[i][j]);
+    HOTK_G6_STEP(l, h)
+    HOTK_G6_STEP(h, l)
+    HOTK_G6_STEP(m, m)
+    HOTK_G6_STEP(m, h)
+    HOTK_G6_STEP(h, m)
+    HOTK_G6_STEP(h, h)
+#undef HOTK_G6_STEP
+  }
+}
+
+// Result tile of a wave (TM x TN accumulators; C/D map: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5))
+// -> global rows.  FULL tiles go through a wave-private LDS image, 32 rows at a time, and leave as 16-byte pieces of
+// 256-byte row runs in straight-line code; tiles that cross the matrix edge store element by element under their guards
+// (one row tile and one column tile of a product at most).
+constexpr int G6_ST = 32 * TN + 4;   // floats per staged row
+__device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc, int64_t row0, int64_t n_rows, int col0,
+                                              int n_cols, const float* __restrict__ bias, unsigned char* lds, int wave, int lane,
+                                              const f32x16 (&acc)[TM][TN], bool full) {
+  const int cl = lane & 31, rh = 4 * (lane >> 5);
+  if (full) {
+    static_assert(TN == 2, "16 lanes x 16 bytes span the staged row");
+    float* st = reinterpret_cast<float*>(lds) + wave * (32 * G6_ST);
+    const int row = lane >> 4, c4 = lane & 15;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (bias) b4 = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) st[((r & 3) + 8 * (r >> 2) + rh) * G6_ST + 32 * j + cl] = acc[i][j][r];
+      __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        float4 v = *reinterpret_cast<const float4*>(st + (4 * q + row) * G6_ST + 4 * c4);
+        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        *reinterpret_cast<float4*>(C + (row0 + 32 * i + 4 * q + row) * ldc + col0 + 4 * c4) = v;
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = 32 * j + cl;
+    if (n >= n_cols) continue;
+    const float b = bias ? bias[col0 + n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t rr = 32 * i + rh + (r & 3) + 8 * (r >> 2);
+        if (rr < n_rows) C[(row0 + rr) * ldc + col0 + n] = acc[i][j][r] + b;
+      }
+  }
+}
+
+// ---- weight -> bf16 planes [3][N][K] (k contiguous): plane[p][n][k] = split_p(trans ? W[k][n] : W[n][k]) ------------
+__global__ void k_gemm6_split_weight(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
+                                     uint16_t* __restrict__ planes) {
+  const int64_t total = (int64_t)N * (K / 2);
+  uint32_t* p32 = reinterpret_cast<uint32_t*>(planes);
+  const int64_t P = (int64_t)N * K / 2;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    // consecutive threads walk the contiguous dimension of W: n when W is [K, N], k when it is [N, K]
+    int n, k;
+    if (trans) {
+      k = 2 * (int)(t / N);
+      n = (int)(t - (int64_t)(k / 2) * N);
+    } else {
+      n = (int)(t / (K / 2));
+      k = 2 * (int)(t - (int64_t)n * (K / 2));
+    }
+    const float x0 = trans ? W[(int64_t)k * ldw + n] : W[(int64_t)n * ldw + k];
+    const float x1 = trans ? W[(int64_t)(k + 1) * ldw + n] : W[(int64_t)n * ldw + k + 1];
+    uint32_t hi, mid, lo;
+    g6_split_pair(x0, x1, hi, mid, lo);
+    const int64_t o = ((int64_t)n * K + k) / 2;
+    p32[o] = hi;
+    p32[P + o] = mid;
+    p32[2 * P + o] = lo;
+  }
+}
+
+// ---- C = A . B (+ bias) ----------------------------------------------------------------------------------------------
+// Piece pi of a tile = (row or column pi & 7 + 8 (pi >> 5), quarter (pi >> 3) & 3 of the 32 k): 8 floats of A (two 16-byte
+// loads, one 16-byte LDS write per plane after the split) or 8 bf16 per plane of B (one 16-byte load and write per plane).
+// Eight consecutive lanes write the same quarter of eight consecutive rows: 80-byte rows put them on distinct banks.
+struct NNRaw { u32x4 a[AP][2]; u32x4 b[BP][3]; };
+constexpr int NN_LOADS = 2 * AP + 3 * BP;      // loads per set
+
+__device__ __forceinline__ int g6_piece_row(int pi) { return (pi & 7) + 8 * (pi >> 5); }
+__device__ __forceinline__ int g6_piece_quarter(int pi) { return (pi >> 3) & 3; }
+
+__device__ __forceinline__ void g6_load_nn(const float* const (&ap)[AP], const uint16_t* const (&bp)[BP], int64_t PL, int k0,
+                                           NNRaw& raw) {
+#pragma unroll
+  for (int q = 0; q < AP; ++q) {
+    g6_ld16(raw.a[q][0], ap[q] + k0);
+    g6_ld16(raw.a[q][1], ap[q] + k0 + 4);
+  }
+#pragma unroll
+  for (int q = 0; q < BP; ++q)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) g6_ld16(raw.b[q][p], bp[q] + p * PL + k0);
+}
+
+// wait until this set (the oldest of DEPTH in flight) has arrived
+__device__ __forceinline__ void g6_wait_nn(NNRaw& raw) {
+  g6_wait_vm<(DEPTH - 1) * NN_LOADS>();
+#pragma unroll
+  for (int q = 0; q < AP; ++q) {
+    g6_arrived(raw.a[q][0]);
+    g6_arrived(raw.a[q][1]);
+  }
+#pragma unroll
+  for (int q = 0; q < BP; ++q)
+#pragma unroll
+    for (int p = 0; p < 3; ++p) g6_arrived(raw.b[q][p]);
+}
+
+__device__ __forceinline__ void g6_store_nn(unsigned char* lds_a, unsigned char* lds_b, int t, const NNRaw& raw) {
+#pragma unroll
+  for (int q = 0; q < AP; ++q) {
+    const int pi = t + q * G6_THREADS;
+    const int off = g6_piece_row(pi) * ROWB + g6_piece_quarter(pi) * 16;
+    const u32x4 x = raw.a[q][0], y = raw.a[q][1];
+    uint32_t h[4], m[4], l[4];
+    g6_split_pair(g6_u2f(x[0]), g6_u2f(x[1]), h[0], m[0], l[0]);
+    g6_split_pair(g6_u2f(x[2]), g6_u2f(x[3]), h[1], m[1], l[1]);
+    g6_split_pair(g6_u2f(y[0]), g6_u2f(y[1]), h[2], m[2], l[2]);
+    g6_split_pair(g6_u2f(y[2]), g6_u2f(y[3]), h[3], m[3], l[3]);
+    *reinterpret_cast<u32x4*>(lds_a + off) = (u32x4){h[0], h[1], h[2], h[3]};
+    *reinterpret_cast<u32x4*>(lds_a + PLANE_A + off) = (u32x4){m[0], m[1], m[2], m[3]};
+    *reinterpret_cast<u32x4*>(lds_a + 2 * PLANE_A + off) = (u32x4){l[0], l[1], l[2], l[3]};
+  }
+#pragma unroll
+  for (int q = 0; q < BP; ++q) {
+    const int pi = t + q * G6_THREADS;
+    const int off = g6_piece_row(pi) * ROWB + g6_piece_quarter(pi) * 16;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4*>(lds_b + p * PLANE_B + off) = raw.b[q][p];
+  }
+}
+
+__global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const float* __restrict__ A, int64_t lda,
+                                                                      const uint16_t* __restrict__ planes,
+                                                                      const float* __restrict__ bias, float* __restrict__ C,
+                                                                      int64_t ldc, int64_t M, int K, int N, int tiles_n) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* lds_a = lds;
+  unsigned char* lds_b = lds + OPER_A;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+  // column tiles of one row tile are neighbours in the grid: the A rows they share stay in L2
+  const int64_t tile = blockIdx.x;
+  const int64_t tm = tile / tiles_n;
+  const int tn = (int)(tile - tm * tiles_n);
+  const int64_t m0 = tm * BM;
+  const int n0 = tn * BN;
+  const int64_t PL = (int64_t)N * K;            // bf16 elements per plane
+  const float* ap[AP];
+  const uint16_t* bp[BP];
+#pragma unroll
+  for (int q = 0; q < AP; ++q) {
+    const int pi = t + q * G6_THREADS;
+    int64_t arow = m0 + g6_piece_row(pi);
+    if (arow >= M) arow = M - 1;
+    ap[q] = A + arow * lda + 8 * g6_piece_quarter(pi);
+  }
+#pragma unroll
+  for (int q = 0; q < BP; ++q) {
+    const int pi = t + q * G6_THREADS;
+    int bn = n0 + g6_piece_row(pi);
+    if (bn >= N) bn = N - 1;
+    bp[q] = planes + (int64_t)bn * K + 8 * g6_piece_quarter(pi);
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // Operands of DEPTH k steps are in flight in registers (a ring of sets).  Every load is unconditional (steps past K
+  // re-read the last one and skip their products), so exactly (DEPTH - 1) NN_LOADS younger loads are outstanding at a wait.
+  const int klast = K - BK;
+  NNRaw ring[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) g6_load_nn(ap, bp, PL, d * BK < K ? d * BK : klast, ring[d]);
+  for (int k0 = 0; k0 < K; k0 += DEPTH * BK) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int kk = k0 + d * BK;
+      g6_wait_nn(ring[d]);
+      g6_store_nn(lds_a, lds_b, t, ring[d]);
+      __syncthreads();
+      g6_load_nn(ap, bp, PL, HOTK_G6_PROBE_KSEL(kk + DEPTH * BK < K ? kk + DEPTH * BK : klast), ring[d]);
+      if (HOTK_G6_PROBE_PROD(kk < K, kk == 0)) g6_products(lds_a, lds_b, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  }
+  g6_drain();
+  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                    (!bias || ((uintptr_t)bias & 15) == 0);
+  g6_store_tile(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), bias, lds, wave,
+                lane, acc, full);
+}
+
+// ---- P[s] = A[rows of slab s]^T . G[rows of slab s] -------------------------------------------------------------------
+// Both operands are read row-major and must enter the MFMA with the ROW index as its k: the LDS planes are [k or n][32
+// rows], written as packed row PAIRS: thread (row pair mp = t & 15, column group cg = t >> 4) loads 4 consecutive columns
+// of its two rows and writes, per column and plane, one 32-bit word (rows 2 mp, 2 mp + 1) -- 16 consecutive lanes fill 64
+// contiguous bytes of one LDS row.  The threads cover G6_THREADS / 4 columns per pass.
+constexpr int T_COLS = G6_THREADS / 4;
+constexpr int TPA = BM / T_COLS, TPG = BN / T_COLS;   // column passes over the A tile / the G tile
+static_assert(TPA * T_COLS == BM && TPG * T_COLS == BN, "column passes cover the tile");
+struct TRaw { u32x4 a[TPA][2], g[TPG][2]; };   // [column pass][row of the pair]
+constexpr int TN_LOADS = 2 * (TPA + TPG);
+
+// in0 / in1: whether the two rows of the pair lie inside the slab (rows past it enter as zeros)
+template <int NP>
+__device__ __forceinline__ void g6_store_t(unsigned char* oper, int plane, int t, const u32x4 (&v)[NP][2], bool in0, bool in1) {
+  const int mp = t & 15, cg = t >> 4;
+#pragma unroll
+  for (int pass = 0; pass < NP; ++pass) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      uint32_t hi, mid, lo;
+      g6_split_pair(in0 ? g6_u2f(v[pass][0][c]) : 0.f, in1 ? g6_u2f(v[pass][1][c]) : 0.f, hi, mid, lo);
+      unsigned char* p = oper + (T_COLS * pass + 4 * cg + c) * ROWB + mp * 4;
+      *reinterpret_cast<uint32_t*>(p) = hi;
+      *reinterpret_cast<uint32_t*>(p + plane) = mid;
+      *reinterpret_cast<uint32_t*>(p + 2 * plane) = lo;
+    }
+  }
+}
+
+// rows `row`, `row + 1` of the step (addresses clamped into the slab)
+__device__ __forceinline__ void g6_load_tn(const float* __restrict__ A, int64_t lda, const float* __restrict__ G, int64_t ldg,
+                                           int64_t row, int64_t r1, const int (&ka)[TPA], const int (&na)[TPG], TRaw& raw) {
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    const int64_t rc = row + w < r1 ? row + w : r1 - 1;
+#pragma unroll
+    for (int pass = 0; pass < TPA; ++pass) g6_ld16(raw.a[pass][w], A + rc * lda + ka[pass]);
+#pragma unroll
+    for (int pass = 0; pass < TPG; ++pass) g6_ld16(raw.g[pass][w], G + rc * ldg + na[pass]);
+  }
+}
+
+__device__ __forceinline__ void g6_wait_tn(TRaw& raw) {
+  g6_wait_vm<(DEPTH - 1) * TN_LOADS>();
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+#pragma unroll
+    for (int pass = 0; pass < TPA; ++pass) g6_arrived(raw.a[pass][w]);
+#pragma unroll
+    for (int pass = 0; pass < TPG; ++pass) g6_arrived(raw.g[pass][w]);
+  }
+}
+
+__global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ G, int64_t ldg,
+                                                                      float* __restrict__ partial, int64_t M, int K, int N,
+                                                                      int tiles_k, int tiles_n, int64_t rows_per_slab) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  unsigned char* lds_a = lds;
+  unsigned char* lds_b = lds + OPER_A;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+  const int64_t bid = blockIdx.x;
+  const int64_t slab = bid / (tiles_k * tiles_n);
+  const int rem = (int)(bid - slab * (tiles_k * tiles_n));
+  const int tk = rem / tiles_n, tn = rem - tk * tiles_n;
+  const int k0 = tk * BM, n0 = tn * BN;
+  const int64_t r0 = slab * rows_per_slab;
+  int64_t r1 = r0 + rows_per_slab;
+  if (r1 > M) r1 = M;
+  const int mp = t & 15, cg = t >> 4;
+  // columns past the end of a partial tile read the last valid column group (their products land in rows / columns that
+  // are never stored)
+  int ka[TPA], na[TPG];
+#pragma unroll
+  for (int pass = 0; pass < TPA; ++pass) {
+    ka[pass] = k0 + T_COLS * pass + 4 * cg;
+    if (ka[pass] + 4 > K) ka[pass] = K - 4;
+  }
+#pragma unroll
+  for (int pass = 0; pass < TPG; ++pass) {
+    na[pass] = n0 + T_COLS * pass + 4 * cg;
+    if (na[pass] + 4 > N) na[pass] = N - 4;
+  }
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // DEPTH 32-row steps in flight in registers, as in k_gemm6_nn; steps past the slab re-read its last row and enter as zeros
+  TRaw ring[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) g6_load_tn(A, lda, G, ldg, r0 + d * BK + 2 * mp, r1, ka, na, ring[d]);
+  for (int64_t m = r0; m < r1; m += DEPTH * BK) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int64_t mm = m + d * BK;
+      g6_wait_tn(ring[d]);
+      const bool in0 = mm + 2 * mp < r1, in1 = mm + 2 * mp + 1 < r1;
+      g6_store_t<TPA>(lds_a, PLANE_A, t, ring[d].a, in0, in1);
+      g6_store_t<TPG>(lds_b, PLANE_B, t, ring[d].g, in0, in1);
+      __syncthreads();
+      g6_load_tn(A, lda, G, ldg, mm + DEPTH * BK + 2 * mp, r1, ka, na, ring[d]);
+      if (mm < r1) g6_products(lds_a, lds_b, wm, wn, lane, acc);
+      __syncthreads();
+    }
+  }
+  g6_drain();
+  float* P = partial + slab * (int64_t)K * N;
+  const bool full = (k0 + BM <= K) && (n0 + BN <= N) && (N & 3) == 0 && ((uintptr_t)partial & 15) == 0;
+  g6_store_tile(P, N, k0 + 32 * TM * wm, K - (k0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), nullptr, lds, wave,
+                lane, acc, full);
+}
+
+// operand planes of a k step, re-used by the epilogue as one 32-row staging image per wave
+constexpr size_t G6_STAGE = (size_t)WM * WN * 32 * G6_ST * sizeof(float);
+constexpr size_t G6_LDS = (size_t)(OPER_A + OPER_B) > G6_STAGE ? (size_t)(OPER_A + OPER_B) : G6_STAGE;
+static_assert(HOTK_G6_WGS * G6_LDS <= 160 * 1024, "LDS of the workgroups of a CU");
+
+int g6_slabs(int64_t M, int64_t K, int64_t N, int64_t* rows_per_slab) {
+  const int64_t tiles = ((K + BM - 1) / BM) * ((N + BN - 1) / BN);
+  // enough workgroups for two per CU, slabs of at least 1 024 rows (a multiple of the 32-row step)
+  int64_t s = (2 * 256 + tiles - 1) / tiles;
+  const int64_t max_s = (M + 1023) / 1024;
+  if (s > max_s) s = max_s;
+  if (s < 1) s = 1;
+  int64_t rps = (M + s - 1) / s;
+  rps = (rps + BK - 1) / BK * BK;
+  *rows_per_slab = rps;
+  return (int)((M + rps - 1) / rps);
+}
+
+template <class F>
+int g6_attr(F f) {
+  return hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)G6_LDS) == hipSuccess ? HOTK_OK
+                                                                                                                    : HOTK_ELAUNCH;
+}
+
+}  // namespace
+
+extern "C" int hotk_gemm6_nn_supported(int64_t M, int64_t K, int64_t N) {
+  return (M > 0 && K >= 32 && K % 32 == 0 && N >= 1 && K <= (1 << 20) && N <= (1 << 20) && M < ((int64_t)1 << 40)) ? 1 : 0;
+}
+
+extern "C" int hotk_gemm6_tn_supported(int64_t M, int64_t K, int64_t N) {
+  return (M > 0 && K >= 4 && K % 4 == 0 && N >= 4 && N % 4 == 0 && K <= (1 << 20) && N <= (1 << 20)) ? 1 : 0;
+}
+
+extern "C" int hotk_gemm6_split_weight(const float* W, int64_t ldw, int64_t K, int64_t N, int transposed, void* planes,
+                                       void* stream) {
+  HOTK_CHECK_ARG(W && planes && K > 0 && N > 0 && K % 2 == 0 && ldw >= (transposed ? N : K));
+  hipLaunchKernelGGL(k_gemm6_split_weight, dim3(hotk_grid(N * (K / 2), 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, (int)K,
+                     (int)N, transposed, (uint16_t*)planes);
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
+                             int64_t M, int64_t K, int64_t N, void* stream) {
+  HOTK_CHECK_ARG(M >= 0 && lda >= K && ldc >= N);
+  if (M == 0) return HOTK_OK;
+  if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
+  HOTK_CHECK_ARG(A && planes && C && hotk_aligned16(A) && hotk_aligned16(planes) && (lda & 3) == 0);
+  static int attr = g6_attr(k_gemm6_nn);
+  if (attr) return attr;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_gemm6_nn, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, (hipStream_t)stream, A, lda,
+                     (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
+  return hotk_launch_status();
+}
+
+extern "C" int hotk_gemm6_tn_partials(int64_t M, int64_t K, int64_t N, int64_t* n_partials) {
+  HOTK_CHECK_ARG(n_partials && M >= 0 && K > 0 && N > 0);
+  int64_t rps;
+  *n_partials = M == 0 ? 1 : g6_slabs(M, K, N, &rps);
+  return HOTK_OK;
+}
+
+extern "C" int hotk_gemm6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K,
+                             int64_t N, void* stream) {
+  HOTK_CHECK_ARG(M >= 0 && lda >= K && ldg >= N && partial);
+  hipStream_t st = (hipStream_t)stream;
+  if (M == 0) return hipMemsetAsync(partial, 0, (size_t)K * N * sizeof(float), st) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
+  if (!hotk_gemm6_tn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
+  HOTK_CHECK_ARG(A && G && hotk_aligned16(A) && hotk_aligned16(G) && ((lda | ldg) & 3) == 0);
+  static int attr = g6_attr(k_gemm6_tn);
+  if (attr) return attr;
+  int64_t rps;
+  const int slabs = g6_slabs(M, K, N, &rps);
+  const int tiles_k = (int)((K + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  hipLaunchKernelGGL(k_gemm6_tn, dim3((unsigned)((int64_t)slabs * tiles_k * tiles_n)), dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg,
+                     partial, M, (int)K, (int)N, tiles_k, tiles_n, rps);
+  return hotk_launch_status();
+}

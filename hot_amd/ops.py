@@ -293,6 +293,63 @@ def thin_gemm_bf16(A, W, bias=None):
 
 
 # ------------------------------------------------------------------------------------------------
+# wide dense projections: fp32-exact tiled GEMMs on the bf16 matrix pipe (csrc/gemm6.hip)
+# ------------------------------------------------------------------------------------------------
+_G6 = os.environ.get('HOTK_GEMM6', '1') == '1'
+G6_MIN_ROWS = 16384       # below: launch-bound either way, the library call is one launch instead of two
+
+
+def _row_major(t):
+    """(tensor, leading dimension) of a 2-D operand readable as rows (a column slice of a wider row-major tensor is fine)"""
+    if t.dim() != 2 or t.stride(1) != 1 or t.stride(0) < t.size(1) or t.stride(0) % 4 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t, t.stride(0) if t.size(0) > 1 else t.size(1)
+
+
+def mm6_ok(A, K, N):
+    return (_G6 and A.is_cuda and A.dtype == torch.float32 and A.dim() == 2 and A.size(0) >= G6_MIN_ROWS and K % 32 == 0
+            and K >= 128 and N >= 96)
+
+
+def mm(A, W, bias=None, trans_w=False):
+    """A[M, K] @ W[K, N] (+ bias), or A[M, K] @ W[N, K]^T with trans_w: the split-bf16 tiled GEMM for tall, wide products
+    (fp32-exact: six bf16 MFMAs per product on three-way exact splits, weight split once per call), the library otherwise"""
+    K = A.size(1)
+    N = W.size(0) if trans_w else W.size(1)
+    assert (W.size(1) if trans_w else W.size(0)) == K
+    if not mm6_ok(A, K, N) or W.dtype != torch.float32:
+        Wm = W.t() if trans_w else W
+        return torch.addmm(bias, A, Wm) if bias is not None else A @ Wm
+    a, lda = _row_major(A)
+    M = a.size(0)
+    if W.stride(1) != 1 and W.stride(0) == 1:      # a transposed VIEW of a row-major weight: read the storage as it lies
+        W, trans_w = W.t(), not trans_w
+    w, ldw = _row_major(W)
+    planes = torch.empty(3, N, K, dtype=torch.bfloat16, device=A.device)
+    call('hotk_gemm6_split_weight', 10 * K * N, p(w), ldw, K, N, 0 if trans_w else 1, p(planes))
+    C = torch.empty(M, N, dtype=torch.float32, device=A.device)
+    call('hotk_gemm6_nn', 4 * M * (K + N), p(a), lda, p(planes), p(bias), p(C), N, M, K, N)
+    return C
+
+
+def wgrad6_ok(A, B):
+    return (_G6 and A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.size(0) >= G6_MIN_ROWS
+            and A.size(1) >= 128 and A.size(1) % 4 == 0 and B.size(1) >= 64 and B.size(1) % 4 == 0)
+
+
+def wgrad6(A, B):
+    """A^T @ B over the rows (hotk_gemm6_tn): per-slab partial products summed in slab order (reproducible)"""
+    a, lda = _row_major(A)
+    b, ldb = _row_major(B)
+    M, K, N = a.size(0), a.size(1), b.size(1)
+    n = ctypes_long()
+    check(lib().hotk_gemm6_tn_partials(M, K, N, byref(n)), 'hotk_gemm6_tn_partials')
+    part = torch.empty(n.value, K, N, dtype=torch.float32, device=A.device)
+    call('hotk_gemm6_tn', 4 * M * (K + N), p(a), lda, p(b), ldb, p(part), M, K, N)
+    return part[0] if n.value == 1 else part.sum(0)
+
+
+# ------------------------------------------------------------------------------------------------
 # autograd functions
 # ------------------------------------------------------------------------------------------------
 class LayerNormRows(Function):
@@ -574,7 +631,7 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
     dev = xs.device
     xd = gather_rows(xs, plan.diag_pos, plan.Nn)                                   # [Nn, D]
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)               # [D, 3C]
-    yn = xd @ Wn
+    yn = mm(xd, Wn)
     x2 = torch.empty(plan.R, 2 * D, dtype=xs.dtype, device=dev)
     call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
     if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
@@ -583,7 +640,7 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
         call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
              p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
     else:
-        y = x2 @ W[D:3 * D]
+        y = mm(x2, W[D:3 * D])
         call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
              p(b_diag), n, C)
     return y, xd, x2
@@ -612,12 +669,12 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
     dx = dW = None
     if want_dx:
-        dxd = dyn @ Wn.t()
+        dxd = mm(dyn, Wn, trans_w=True)
         if dxd_extra is not None:
             dxd += dxd_extra
         # wide-input data gradient [R, C] x [C, 2D]: the thin kernel's row stream since its two-register-set form
         # (same-box A/B at 10 M rows, C = 288 -> 64: 3.08 ms against 3.46 ms for the library GEMM)
-        dx2 = thin_gemm(g, W[D:3 * D].t()) if (g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)) else g @ W[D:3 * D].t()
+        dx2 = thin_gemm(g, W[D:3 * D].t()) if (g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)) else mm(g, W[D:3 * D], trans_w=True)
         dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
         call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
@@ -674,14 +731,14 @@ class Proj22(Function):
         assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
         h2, xd, x2 = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
         if b1 is not None and not nodes_padded:
-            h1 = torch.addmm(b1, xd, W1)      # no padding node rows: the bias rides on the GEMM, nothing to mask
+            h1 = mm(xd, W1, b1)      # no padding node rows: the bias rides on the GEMM, nothing to mask
         else:
-            h1 = xd @ W1
+            h1 = mm(xd, W1)
             call('hotk_bias_mask_rows', 8 * plan.Nn * h1.size(1), p(h1), h1.size(1), p(plan.nkind), p(None), p(b1), plan.Nn,
                  h1.size(1))
         xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
         wv = Wv.t()
-        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else torch.addmm(bv, xc, wv)
+        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True)
         ctx.save_for_backward(xc, xd, x2, W1, W2, Wv)
         ctx.plan, ctx.xshape, ctx.nodes_padded = plan, x.shape, nodes_padded
         ctx.has_b = (b1 is not None, b2_off is not None, b2_diag is not None)
@@ -698,14 +755,14 @@ class Proj22(Function):
         if linear_bwd_ok(plan.R, D, dv2.size(1)):
             dxv, dwv, dbv = linear_bwd_fused(dv2, xc, wv)
         else:
-            dxv, dwv, dbv = dv2 @ Wv, wgrad(xc, dv2), dv2.sum(0)
+            dxv, dwv, dbv = mm(dv2, Wv), wgrad(xc, dv2), dv2.sum(0)
         # fc_1 (node rows)
         g1 = dh1.contiguous().view(plan.Nn, -1)
         if ctx.nodes_padded:
             g1 = mask_rows(g1, plan.nkind, KEEP_VALID, 0.0)
         db1 = bias_grads(g1, plan.nkind, False, True)[1] if ctx.has_b[0] else None
         dW1 = wgrad(xd, g1)
-        dxd1 = g1 @ W1.t()
+        dxd1 = mm(g1, W1, trans_w=True)
         # fc_2, with the other two gradients of x folded in
         g2 = dh2.contiguous().view(plan.R, -1)
         dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv)
@@ -975,6 +1032,8 @@ def wgrad(A, B):
     A single library GEMM has only K*N/tile workgroups to run on, so the row dimension is split into S batches
     (torch.bmm -> rocBLAS/hipBLASLt batched GEMM) whose partial products are summed: split-K over 256 CUs."""
     R = A.size(0)
+    if wgrad6_ok(A, B):
+        return wgrad6(A, B)
     if R < (1 << 16):
         return (A.t() @ B).float()
     S = 256
@@ -998,7 +1057,7 @@ class RowsMatmul(Function):
         # 2-D result on purpose (a fresh tensor, not a view): callers may finish it in place (BiasMask)
         if x2.is_cuda and x2.dtype == torch.float32 and thin_wide_ok(x2.size(0), x2.size(1), w.size(1)):
             return thin_gemm(x2.contiguous(), w, b)
-        return torch.addmm(b, x2, w) if b is not None else x2 @ w
+        return mm(x2, w, b)
 
     @staticmethod
     def backward(ctx, g):
@@ -1012,7 +1071,7 @@ class RowsMatmul(Function):
             # GEMM, a split-K batched GEMM over [x | 1] and the concatenation that builds it
             dx, dw, db = linear_bwd_fused(g2.contiguous(), x2.contiguous(), w)
             return dx.view(x.shape), dw, (db if want_b else None)
-        dx = (g2 @ w.t()).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = mm(g2, w, trans_w=True).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1] and want_b and g2.size(1) > 2 * x2.size(1) and x2.size(0) >= (1 << 16):
             # g is the wide operand: [x | 1]^T @ g yields dW and db in ONE pass over g
@@ -1127,7 +1186,7 @@ class AttnCore22(Function):
         if not padded and thin_ok(plan.R, 320, D):
             out = thin_gemm(att, w_o.t(), b_o, skip).view(*h2.shape[:-1], D)      # projection + bias + skip path in one pass
         else:
-            y = torch.addmm(b_o, att, w_o.t())
+            y = mm(att, w_o, b_o, trans_w=True)
             if padded:
                 y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
             out = y.add_(skip).view(*h2.shape[:-1], D)
@@ -1156,7 +1215,7 @@ class AttnCore22(Function):
         d_out = d_out.contiguous().view(plan.R, D)
         padded = plan.Ev != plan.R
         dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
-        datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else dy @ w_o
+        datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else mm(dy, w_o)
         # att as saved = the (dropped-out) input of fc_o.  dW_o = dy^T . att in the weight-gradient-only mode of
         # hotk_linear_bwd_fused (x = dy, g = att): 3.65 ms against 3.41 ms for the split-K batched GEMM before that
         # kernel's loads were made unconditional, measured again after

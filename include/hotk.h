@@ -283,6 +283,25 @@ int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);
 int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K, int64_t C,
                           float* dx, int64_t lddx, float* partial, int64_t R, void* stream);
 
+/* Wide dense projections as fp32-exact tiled GEMMs on the bf16 matrix pipe (csrc/gemm6.hip): every fp32 operand is split
+ * exactly into three bf16 numbers and the six products of relative weight >= 2^-16 are summed in fp32 (1.8e-7 against
+ * fp64, as the library's fp32 GEMM).  replaces the aten mm / addmm calls under nn.Linear and _Weight.get_output for the
+ * shapes the LDS-resident thin GEMM does not take (models/sparse/linear.py:46-48, kernelattn.py:65-72, and their
+ * autograd): C2's hidden widths 256 / 512, the dim_qk = 64 head shape.
+ *   hotk_gemm6_split_weight: planes [3][N][K] bf16 (hi | mid | lo, k contiguous) of the B operand of C = A . B:
+ *       transposed = 1: B = W with W [K, N] row-major (y = x @ W);  0: B = W^T with W [N, K] row-major (nn.Linear, dx = g @ W^T)
+ *   hotk_gemm6_nn: C[M, N] = A[M, K] . B (+ bias[N]);  K % 32 == 0, A rows 16-byte aligned
+ *   hotk_gemm6_tn: partial[s][K][N] = A[rows of slab s]^T . G[rows of slab s], s < hotk_gemm6_tn_partials(M, K, N); the
+ *       caller adds the slabs in order (weight gradient x^T . dy);  K, N % 4 == 0, rows 16-byte aligned */
+int hotk_gemm6_nn_supported(int64_t M, int64_t K, int64_t N);
+int hotk_gemm6_tn_supported(int64_t M, int64_t K, int64_t N);
+int hotk_gemm6_split_weight(const float* W, int64_t ldw, int64_t K, int64_t N, int transposed, void* planes, void* stream);
+int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M,
+                  int64_t K, int64_t N, void* stream);
+int hotk_gemm6_tn_partials(int64_t M, int64_t K, int64_t N, int64_t* n_partials);
+int hotk_gemm6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K, int64_t N,
+                  void* stream);
+
 /* LayerNorm over the rows of a batch with the padding mask folded in: y[r] = (keep >> kind[r]) & 1 ? LN(x[r]) * gamma +
  * beta : 0 (kind NULL: every row), stats[r] = {mean, rstd} for the backward.  replaces Apply(nn.LayerNorm) + batch_like's
  * masked_fill clone in EncLayer (models/encoder.py:36,40-41, sparse/f.py:20-27, utils/set.py:47-48) and, in _bwd, aten's

@@ -965,3 +965,38 @@ def test_layernorm_rows_with_mask_vs_fp64(D):
                 assert float(H.values.detach()[~G.mask].abs().max()) == 0.0 and float(x.grad[~G.mask].abs().max()) == 0.0
             assert rel_err(x.grad.cpu(), xd.grad.cpu()) < 2 * TOL
             assert rel_err(ln.weight.grad.cpu(), wd.grad.cpu()) < 2 * TOL and rel_err(ln.bias.grad.cpu(), bd.grad.cpu()) < 2 * TOL
+
+
+@pytest.mark.parametrize('M,K,N', [(20000, 512, 512), (16400 + 77, 256, 320), (33333, 320, 256), (16384, 128, 96), (40001, 1280, 512)])
+def test_gemm6_products_vs_fp64(M, K, N):
+    """csrc/gemm6.hip: the tall wide projections as six bf16 MFMAs per product on exact three-way splits -- fp32-exact.
+    C = A W (+ bias), C = A W^T, and the weight gradient A^T G, against float64; row counts that are not a multiple of the
+    128-row tile, a width that is not a multiple of the 128-column tile, a strided A (column slice of a wider tensor), a
+    transposed view as the weight.  Bar: 2e-6 of the result's scale (the fp32 library GEMM measures ~5e-7 on these)."""
+    _lib, ops, *_ = _product()
+    g = torch.Generator().manual_seed(M + K + N)
+    wide = torch.randn(M, K + 32, generator=g).to(DEV)
+    A = wide[:, 16:16 + K]                                  # rows 16-byte aligned, leading dimension K + 32
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    assert ops.mm6_ok(A, K, N)
+    _lib.timing_begin(None)
+    y1 = ops.mm(A, W, b)
+    y2 = ops.mm(A, W.t().contiguous(), None, trans_w=True)
+    y3 = ops.mm(A, W.t().contiguous().t())                  # a transposed view of a row-major [N, K] weight
+    ran = _lib.timing_end()
+    assert ran['hotk_gemm6_nn'][1] == 3 and ran['hotk_gemm6_split_weight'][1] == 3
+    ref = A.double() @ W.double()
+    assert rel_err(y1.cpu(), (ref + b.double()).cpu()) < 2e-6
+    assert rel_err(y2.cpu(), ref.cpu()) < 2e-6 and torch.equal(y2, y3)
+    lib_err = rel_err((A @ W).cpu(), ref.cpu())
+    print(f'gemm6 nn [{M},{K}]x[{K},{N}]: {rel_err(y2.cpu(), ref.cpu()):.2e} against fp64 (library fp32 GEMM {lib_err:.2e})')
+    # weight gradient
+    G = torch.randn(M, N, generator=g).to(DEV)
+    assert ops.wgrad6_ok(A, G)
+    _lib.timing_begin(None)
+    dW = ops.wgrad(A, G)
+    assert 'hotk_gemm6_tn' in _lib.timing_end()
+    refw = A.double().t() @ G.double()
+    assert rel_err(dW.cpu(), refw.cpu()) < 2e-6
+    assert torch.equal(dW, ops.wgrad(A, G))                 # slabs are added in a fixed order
