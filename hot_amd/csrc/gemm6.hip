@@ -198,7 +198,9 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
   }
 }
 
-// ---- weight -> bf16 planes [3][N][K] (k contiguous): plane[p][n][k] = split_p(trans ? W[k][n] : W[n][k]) ------------
+// ---- weight -> bf16 planes [3][K / 32][N][32 k]: plane[p][kb][n][kk] = split_p(B[32 kb + kk][n]), B[k][n] = trans ? W[k][n]
+// : W[n][k].  A k step's slice for consecutive columns is one contiguous run of whole cache lines (with k contiguous over
+// all of K a step read 64 bytes out of every 1 KB: half of each line fetched, twice) ------------------------------------
 __global__ void k_gemm6_split_weight(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
                                      uint16_t* __restrict__ planes) {
   const int64_t total = (int64_t)N * (K / 2);
@@ -218,7 +220,7 @@ __global__ void k_gemm6_split_weight(const float* __restrict__ W, int64_t ldw, i
     const float x1 = trans ? W[(int64_t)(k + 1) * ldw + n] : W[(int64_t)n * ldw + k + 1];
     uint32_t hi, mid, lo;
     g6_split_pair(x0, x1, hi, mid, lo);
-    const int64_t o = ((int64_t)n * K + k) / 2;
+    const int64_t o = (((int64_t)(k >> 5) * N + n) * 32 + (k & 31)) / 2;
     p32[o] = hi;
     p32[P + o] = mid;
     p32[2 * P + o] = lo;
@@ -235,8 +237,8 @@ constexpr int NN_LOADS = 2 * AP + 3 * BP;      // loads per set
 __device__ __forceinline__ int g6_piece_row(int pi) { return (pi & 7) + 8 * (pi >> 5); }
 __device__ __forceinline__ int g6_piece_quarter(int pi) { return (pi >> 3) & 3; }
 
-__device__ __forceinline__ void g6_load_nn(const float* const (&ap)[AP], const uint16_t* const (&bp)[BP], int64_t PL, int k0,
-                                           NNRaw& raw) {
+__device__ __forceinline__ void g6_load_nn(const float* const (&ap)[AP], const uint16_t* const (&bp)[BP], int64_t PL, int Nld,
+                                           int k0, NNRaw& raw) {
 #pragma unroll
   for (int q = 0; q < AP; ++q) {
     g6_ld16(raw.a[q][0], ap[q] + k0);
@@ -245,7 +247,7 @@ __device__ __forceinline__ void g6_load_nn(const float* const (&ap)[AP], const u
 #pragma unroll
   for (int q = 0; q < BP; ++q)
 #pragma unroll
-    for (int p = 0; p < 3; ++p) g6_ld16(raw.b[q][p], bp[q] + p * PL + k0);
+    for (int p = 0; p < 3; ++p) g6_ld16(raw.b[q][p], bp[q] + p * PL + (int64_t)k0 * Nld);
 }
 
 // wait until this set (the oldest of DEPTH in flight) has arrived
@@ -315,7 +317,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     const int pi = t + q * G6_THREADS;
     int bn = n0 + g6_piece_row(pi);
     if (bn >= N) bn = N - 1;
-    bp[q] = planes + (int64_t)bn * K + 8 * g6_piece_quarter(pi);
+    bp[q] = planes + (int64_t)bn * 32 + 8 * g6_piece_quarter(pi);      // + k0 * N per step: planes are [K / 32][N][32]
   }
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
   const int klast = K - BK;
   NNRaw ring[DEPTH];
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) g6_load_nn(ap, bp, PL, d * BK < K ? d * BK : klast, ring[d]);
+  for (int d = 0; d < DEPTH; ++d) g6_load_nn(ap, bp, PL, N, d * BK < K ? d * BK : klast, ring[d]);
   for (int k0 = 0; k0 < K; k0 += DEPTH * BK) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
@@ -337,7 +339,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
       g6_wait_nn(ring[d]);
       g6_store_nn(lds_a, lds_b, t, ring[d]);
       __syncthreads();
-      g6_load_nn(ap, bp, PL, HOTK_G6_PROBE_KSEL(kk + DEPTH * BK < K ? kk + DEPTH * BK : klast), ring[d]);
+      g6_load_nn(ap, bp, PL, N, HOTK_G6_PROBE_KSEL(kk + DEPTH * BK < K ? kk + DEPTH * BK : klast), ring[d]);
       if (HOTK_G6_PROBE_PROD(kk < K, kk == 0)) g6_products(lds_a, lds_b, wm, wn, lane, acc);
       __syncthreads();
     }

@@ -333,8 +333,12 @@ def mm(A, W, bias=None, trans_w=False):
 
 
 def wgrad6_ok(A, B):
+    """tall operands whose product fills the 256 x 256 tiles (measured at 254 k rows: [., 512]^T [., 256] 172 against 131
+    TFLOP/s for the library's split-K batch, [., 256]^T [., 864] 162 / 122; below 256 columns on either side the tile is
+    mostly padding: [., 128]^T [., 576] 75 / 118)"""
+    K, N = A.size(1), B.size(1)
     return (_G6 and A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.size(0) >= G6_MIN_ROWS
-            and A.size(1) >= 128 and A.size(1) % 4 == 0 and B.size(1) >= 64 and B.size(1) % 4 == 0)
+            and K >= 256 and N >= 256 and K * N >= 512 * 256 and K % 4 == 0 and N % 4 == 0)
 
 
 def wgrad6(A, B):
@@ -680,7 +684,10 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
     if want_dw:
         if ones_row:
-            dWn = wgrad(torch.cat([xd, torch.ones(xd.size(0), 1, dtype=xd.dtype, device=dev)], dim=1), dyn)
+            # (the ones column padded to four: rows of [xd | 1 0 0 0] stay 16-byte aligned for the tiled weight-gradient GEMM)
+            one = torch.zeros(xd.size(0), 4, dtype=xd.dtype, device=dev)
+            one[:, 0] = 1.
+            dWn = wgrad(torch.cat([xd, one], dim=1), dyn)
             db_diag = dWn[D, 0:C] if has_b[1] else None
             db_off = dWn[D, C:2 * C] if has_b[0] else None
             dWn = dWn[:D]

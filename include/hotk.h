@@ -288,7 +288,7 @@ int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t l
  * fp64, as the library's fp32 GEMM).  replaces the aten mm / addmm calls under nn.Linear and _Weight.get_output for the
  * shapes the LDS-resident thin GEMM does not take (models/sparse/linear.py:46-48, kernelattn.py:65-72, and their
  * autograd): C2's hidden widths 256 / 512, the dim_qk = 64 head shape.
- *   hotk_gemm6_split_weight: planes [3][N][K] bf16 (hi | mid | lo, k contiguous) of the B operand of C = A . B:
+ *   hotk_gemm6_split_weight: planes [3][K / 32][N][32] bf16 (hi | mid | lo; 3 N K elements) of the B operand of C = A . B:
  *       transposed = 1: B = W with W [K, N] row-major (y = x @ W);  0: B = W^T with W [N, K] row-major (nn.Linear, dx = g @ W^T)
  *   hotk_gemm6_nn: C[M, N] = A[M, K] . B (+ bias[N]);  K % 32 == 0, A rows 16-byte aligned
  *   hotk_gemm6_tn: partial[s][K][N] = A[rows of slab s]^T . G[rows of slab s], s < hotk_gemm6_tn_partials(M, K, N); the

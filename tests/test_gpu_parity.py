@@ -993,10 +993,11 @@ def test_gemm6_products_vs_fp64(M, K, N):
     print(f'gemm6 nn [{M},{K}]x[{K},{N}]: {rel_err(y2.cpu(), ref.cpu()):.2e} against fp64 (library fp32 GEMM {lib_err:.2e})')
     # weight gradient
     G = torch.randn(M, N, generator=g).to(DEV)
-    assert ops.wgrad6_ok(A, G)
     _lib.timing_begin(None)
-    dW = ops.wgrad(A, G)
+    dW = ops.wgrad6(A, G)                                    # (ops.wgrad takes it for the shapes that fill its tiles)
     assert 'hotk_gemm6_tn' in _lib.timing_end()
     refw = A.double().t() @ G.double()
     assert rel_err(dW.cpu(), refw.cpu()) < 2e-6
-    assert torch.equal(dW, ops.wgrad(A, G))                 # slabs are added in a fixed order
+    assert torch.equal(dW, ops.wgrad6(A, G))                # slabs are added in a fixed order
+    assert ops.wgrad6_ok(A, G) == (K >= 256 and N >= 256 and K * N >= 512 * 256)
+    assert rel_err(ops.wgrad(A, G).cpu(), refw.cpu()) < TOL          # (the library fallback for the other shapes: its own fp32 error)
