@@ -278,6 +278,115 @@ def dry_launch(args, world, rank, dist):
         dist.destroy_process_group()
 
 
+def c2_mode(args, device, world, rank, dist):
+    """--config c2: BASELINE config 2, the PCQM4M-LSC enc-small training step (regression/examples/pcqm4m-lsc/enc-small.sh:
+    Encoder(2, 0, [2]*8, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel'), 14.06 M parameters)
+    on --molecules synthetic PCQM-like graphs per GPU (n ~ U{8..20} atoms, ~1.05 n bonds, symmetrised; the
+    shipped per-GPU batch is 128), forward + L1 loss backward, fixed projections.  A second line, never the headline: the
+    headline metric is the 2->2 layer on 10 M entries.  One GPU: the whole step is captured once into a HIP graph and
+    replayed (every launch goes to torch's current stream, nothing allocates outside the caching allocator); several GPUs:
+    eager steps with the parameter gradients all-reduced (graph-minibatch data parallelism)."""
+    from hot_amd import _lib
+    from hot_amd.batch.sparse import make_batch_concatenated
+    from hot_amd.dist import allreduce_gradients, max_over_ranks
+    from hot_amd.models.encoder import Encoder
+    rng = np.random.default_rng(1000 + rank)
+    nn_, ne_, eis = [], [], []
+    for _ in range(args.molecules):
+        n = int(rng.integers(8, 21))
+        und = {(i, i + 1) for i in range(n - 1)}
+        while len(und) < int(round(1.05 * n)):
+            i, j = sorted(int(v) for v in rng.integers(0, n, 2))
+            if i != j:
+                und.add((i, j))
+        e = sorted([(i, j) for i, j in und] + [(j, i) for i, j in und])
+        eis.append(np.array(e, dtype=np.int64).T); nn_.append(n); ne_.append(len(e))
+    ei = torch.from_numpy(np.concatenate(eis, axis=1)).to(device)
+    g = torch.Generator(device=device).manual_seed(77 + rank)
+    nf = torch.randn(sum(nn_), 256, device=device, generator=g)
+    ef = torch.randn(sum(ne_), 256, device=device, generator=g)
+    G = make_batch_concatenated(nf, ei, ef, nn_, ne_)
+    torch.manual_seed(0)
+    enc = Encoder(2, 0, [2] * 8, 512, 256, 256, 32, 32, 256, 4, 128, 128, 8, 'default', 'generalized_kernel', 0., 0., 0.,
+                  sparse=True).to(device)
+    enc.skip_redraw_projections = True
+    head = torch.nn.Linear(256, 1).to(device)
+    params = list(enc.parameters()) + list(head.parameters())
+    n_entries = sum(G.n_edges)
+
+    def fwd_bwd():
+        y = head(enc(G)).squeeze(-1)
+        torch.nn.functional.l1_loss(y, torch.zeros_like(y)).backward()
+
+    def step():
+        fwd_bwd()
+        if dist is not None:
+            allreduce_gradients(params)
+        for p_ in params:
+            p_.grad = None
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 2)):
+        step()
+    fence()
+    _lib.timing_begin(None)
+    step()
+    census = _lib.timing_end()
+    n_kernels = None
+    try:                                    # device kernels of one eager step (library GEMMs and torch glue included)
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step()
+            torch.cuda.synchronize()
+        n_kernels = sum(1 for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA)
+    except Exception:
+        pass
+    replay = dist is None and not args.no_graph
+    if replay:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            fwd_bwd()
+        run = graph.replay
+        for _ in range(3):
+            run()
+    else:
+        run = step
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    fence()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device)
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'entries/sec, PCQM4M-LSC enc-small training step (fwd + L1 loss bwd)', 'value': n_entries * world * args.steps / elapsed,
+            'unit': 'entries/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'C2: enc-small Encoder (8 x 2->2 kernel-attention layers + softmax readout, D = 256, 14.06 M '
+                                   f'parameters), {args.molecules} PCQM-like molecules per GPU = {n_entries} entries '
+                                   f'({G.values.size(0) * G.values.size(1)} padded rows), '
+                                   f'{"HIP-graph replay" if replay else "eager"}',
+                       'entries_per_gpu': n_entries, 'parallelism': f'graph-minibatch dp{world}'},
+            'hotk_launches_per_step': int(sum(v[1] for v in census.values())),
+            'device_kernels_per_step': n_kernels,
+            'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])[:12]},
+            'cpu_reference_entries_per_s': 1.19e3,
+            'cpu_reference_note': 'the real reference on 8 CPU cores, same model, 128 graphs (SURVEY section 6 / BASELINE.md)',
+            'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+        }), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -292,6 +401,11 @@ def main():
                          "2e-2). A second line, never the headline: the reference trains in fp32")
     ap.add_argument('--shard-nodes', type=int, default=125000, help='edge-shard mode: nodes per GPU')
     ap.add_argument('--shard-pairs', type=int, default=3125000, help='edge-shard mode: undirected pairs per GPU')
+    ap.add_argument('--config', default='c1', choices=['c1', 'c2'],
+                    help='c1 (default, the headline): the 2->2 layer on ~10 M entries of BA(64,5) graphs; c2: the PCQM4M-LSC '
+                         'enc-small training step (a second line)')
+    ap.add_argument('--molecules', type=int, default=128, help='--config c2: molecules per GPU (enc-small.sh ships 128)')
+    ap.add_argument('--no-graph', action='store_true', help='--config c2: eager steps instead of HIP-graph replay')
     ap.add_argument('--sweep', action='store_true', help='run_perf_tests.py-style size sweep (SK / SL curves) instead')
     ap.add_argument('--sweep-max-n', type=int, default=None)
     args = ap.parse_args()
@@ -337,6 +451,12 @@ def main():
     if args.sweep:
         if rank == 0:
             print(json.dumps(sweep(device, n_max=args.sweep_max_n)), flush=True)
+        return
+    if args.config == 'c2':
+        c2_mode(args, device, world, rank, dist)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
         return
     if args.mode == 'edge-shard':
         edge_shard_mode(args, device, world, rank, dist)
