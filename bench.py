@@ -539,7 +539,7 @@ def main():
                     'avg_launch_ms': tot_ms / max(calls, 1),
                     'note': 'achieved = algorithmic bytes (operands read once + results written once) of the '
                             'dominant C-ABI kernel / its HIP-event time inside the timed region; the kernel is '
-                            'instruction-issue bound (VALU 86 % busy; L2 -> fabric traffic 1.4-1.5x algorithmic), see DESIGN.md 4'}
+                            'instruction-issue bound (VALU 86 % busy; L2 -> fabric traffic 1.4-1.6x algorithmic), see DESIGN.md 4'}
         line = {
             'metric': 'edges/sec fwd+bwd, 2->2 sparse kernel attn layer', 'value': value, 'unit': 'entries/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3,

@@ -1225,7 +1225,7 @@ class AttnCore22(Function):
         datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else mm(dy, w_o)
         # att as saved = the (dropped-out) input of fc_o.  dW_o = dy^T . att in the weight-gradient-only mode of
         # hotk_linear_bwd_fused (x = dy, g = att): 3.65 ms against 3.41 ms for the split-K batched GEMM before that
-        # kernel's loads were made unconditional, measured again after
+        # kernel's loads were made unconditional, measured again after (profiles/NOTES_r01_r02.md, old section 5)
         if _DWO_FUSED and dy.dtype == torch.float32 and linear_bwd_ok(plan.R, D, 320):
             dw_o = linear_bwd_fused(att, dy.contiguous(), None)[1]
         else:
