@@ -22,6 +22,7 @@
 // [512, 512] product, and a build with the products compiled out still took 0.94 of its 1.14 ms; a 256 x 256 tile moves half
 // the bytes per product.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -202,7 +203,7 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
 // : W[n][k].  A k step's slice for consecutive columns is one contiguous run of whole cache lines (with k contiguous over
 // all of K a step read 64 bytes out of every 1 KB: half of each line fetched, twice) ------------------------------------
 __global__ void k_gemm6_split_weight(const float* __restrict__ W, int64_t ldw, int K, int N, int trans,
-                                     uint16_t* __restrict__ planes) {
+                                     uint16_t* __restrict__ planes, int kb_log2) {
   const int64_t total = (int64_t)N * (K / 2);
   uint32_t* p32 = reinterpret_cast<uint32_t*>(planes);
   const int64_t P = (int64_t)N * K / 2;
@@ -220,11 +221,21 @@ __global__ void k_gemm6_split_weight(const float* __restrict__ W, int64_t ldw, i
     const float x1 = trans ? W[(int64_t)(k + 1) * ldw + n] : W[(int64_t)n * ldw + k + 1];
     uint32_t hi, mid, lo;
     g6_split_pair(x0, x1, hi, mid, lo);
-    const int64_t o = (((int64_t)(k >> 5) * N + n) * 32 + (k & 31)) / 2;
+    const int64_t o = ((((int64_t)(k >> kb_log2) * N + n) << kb_log2) + (k & ((1 << kb_log2) - 1))) / 2;   // [K / kb][N][kb]
     p32[o] = hi;
     p32[P + o] = mid;
     p32[2 * P + o] = lo;
   }
+}
+
+// tile of workgroup `orig` of `nwg`: the blocks that share an XCD (orig % 8) take consecutive tiles
+__device__ __forceinline__ int64_t g6_xcd_tile(unsigned orig, unsigned nwg) {
+#ifdef HOTK_G6_NOXCD
+  return orig;
+#else
+  const unsigned q = nwg / 8, r = nwg % 8, xcd = orig % 8;
+  return (int64_t)(xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + orig / 8;
+#endif
 }
 
 // ---- C = A . B (+ bias) ----------------------------------------------------------------------------------------------
@@ -296,8 +307,9 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
   unsigned char* lds_a = lds;
   unsigned char* lds_b = lds + OPER_A;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
-  // column tiles of one row tile are neighbours in the grid: the A rows they share stay in L2
-  const int64_t tile = blockIdx.x;
+  // Workgroups b, b + 8, b + 16, .. share an XCD (round-robin dispatch; speed only): consecutive tiles are dealt to the
+  // blocks of ONE XCD, so the column tiles of a row tile read its A rows through the same L2 (bijective remap).
+  const int64_t tile = g6_xcd_tile(blockIdx.x, gridDim.x);
   const int64_t tm = tile / tiles_n;
   const int tn = (int)(tile - tm * tiles_n);
   const int64_t m0 = tm * BM;
@@ -345,6 +357,166 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     }
   }
   g6_drain();
+  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+                    (!bias || ((uintptr_t)bias & 15) == 0);
+  g6_store_tile(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), bias, lds, wave,
+                lane, acc, full);
+}
+
+// ---- C = A . B (+ bias), pipelined form -------------------------------------------------------------------------------
+// The kernel above runs its data phase (loads -> split -> LDS writes -> barrier, ~3 us per k step) and its product phase
+// (1.3 us) one after the other: one workgroup per CU and a barrier per step keep all eight waves in phase.  Here the k step
+// is 16 and LDS holds TWO stages of A planes and THREE of B planes (147 KB), so that stage i + 1 is filled while stage i is
+// multiplied, with ONE barrier per step:
+//   * B planes go global -> LDS by DMA (global_load_lds_dwordx4: no registers, no ds_write), two steps ahead.  A DMA
+//     instruction writes 1 KB lane-linearly, so the B stage is unpadded [plane][column][2 x 16 B] and the bank swizzle of the
+//     fragment reads -- chunk position = k half ^ bit 3 of the column -- is applied to the per-lane SOURCE address;
+//   * A goes through a two-deep register ring (inline-asm loads, hand-counted vmcnt, see above), split and written one
+//     step ahead;
+//   * the barrier is a raw s_barrier behind s_waitcnt lgkmcnt(0): no vmcnt(0), the loads of the next two steps stay in
+//     flight across it.
+// Weight planes for this kernel are [3][K / 16][N][16].
+constexpr int ROWB16 = 48;                               // A stage: 16 bf16 + 16 B padding per row and plane
+constexpr int PLANE16_A = BM * ROWB16, STAGE16_A = 3 * PLANE16_A;
+constexpr int PLANE16_B = BN * 32, STAGE16_B = 3 * PLANE16_B;
+constexpr int P16_A0 = 0, P16_B0 = 2 * STAGE16_A;
+constexpr size_t G6_LDS16 = (size_t)(2 * STAGE16_A + 3 * STAGE16_B);
+static_assert(BN * 32 * 3 == (G6_THREADS / 64) * 3 * 1024, "three DMA instructions per wave fill a B stage");
+static_assert(BM * 2 == G6_THREADS, "one A piece (row, k half) per thread");
+
+// 16 bytes per lane from gsrc to LDS byte address lds_dst + 16 * lane (lds_dst wave-uniform)
+__device__ __forceinline__ void g6_glds16(const void* gsrc, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+// the workgroup barrier of the pipelined loop: this wave's LDS writes and reads are done, nothing is said about vmcnt
+__device__ __forceinline__ void g6_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
+
+__device__ __forceinline__ void g6_products16(const unsigned char* la, const unsigned char* lb, int wm, int wn, int lane,
+                                              f32x16 (&acc)[TM][TN]) {
+  const int r = lane & 31, h = lane >> 5;
+  Frag fa[TM], fb[TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const unsigned char* p = la + (32 * TM * wm + 32 * i + r) * ROWB16 + 16 * h;
+    fa[i].h = *reinterpret_cast<const u32x4*>(p);
+    fa[i].m = *reinterpret_cast<const u32x4*>(p + PLANE16_A);
+    fa[i].l = *reinterpret_cast<const u32x4*>(p + 2 * PLANE16_A);
+  }
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = 32 * TN * wn + 32 * j + r;
+    const unsigned char* p = lb + n * 32 + 16 * (h ^ ((n >> 3) & 1));
+    fb[j].h = *reinterpret_cast<const u32x4*>(p);
+    fb[j].m = *reinterpret_cast<const u32x4*>(p + PLANE16_B);
+    fb[j].l = *reinterpret_cast<const u32x4*>(p + 2 * PLANE16_B);
+  }
+#define HOTK_G6_STEP(PA, PB)                                                     \
+  _Pragma("unroll") for (int i = 0; i < TM; ++i)                                 \
+  _Pragma("unroll") for (int j = 0; j < TN; ++j) acc[i][j] = g6_mfma(fa[i].PA, fb[j].PB, acc[i][j]);
+  HOTK_G6_STEP(l, h)
+  HOTK_G6_STEP(h, l)
+  HOTK_G6_STEP(m, m)
+  HOTK_G6_STEP(m, h)
+  HOTK_G6_STEP(h, m)
+  HOTK_G6_STEP(h, h)
+#undef HOTK_G6_STEP
+}
+
+__global__ __launch_bounds__(G6_THREADS, 1) void k_gemm6_nn16(const float* __restrict__ A, int64_t lda,
+                                                              const uint16_t* __restrict__ planes, const float* __restrict__ bias,
+                                                              float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
+                                                              int tiles_n) {
+  extern __shared__ __align__(16) unsigned char lds[];
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave / WN, wn = wave % WN;
+  const int64_t tile = g6_xcd_tile(blockIdx.x, gridDim.x);
+  const int64_t tm = tile / tiles_n;
+  const int tn = (int)(tile - tm * tiles_n);
+  const int64_t m0 = tm * BM;
+  const int n0 = tn * BN;
+  const int S = K >> 4;                                       // k steps
+  // A piece of this thread: row (t & 7) + 8 (t >> 4), k half (t >> 3) & 1
+  const int arow_l = (t & 7) + 8 * (t >> 4), ahalf = (t >> 3) & 1;
+  int64_t arow = m0 + arow_l;
+  if (arow >= M) arow = M - 1;
+  const float* ap = A + arow * lda + 8 * ahalf;
+  const int aoff = arow_l * ROWB16 + 16 * ahalf;
+  // B: this wave's DMA covers columns 32 wave .. 32 wave + 31; lane -> (column, chunk position); source chunk swizzled
+  const int bn_l = 32 * wave + (lane >> 1);
+  int bn = n0 + bn_l;
+  if (bn >= N) bn = N - 1;
+  const int bchunk = (lane & 1) ^ ((bn_l >> 3) & 1);
+  const int64_t PL = (int64_t)N * K;                          // bf16 elements per plane
+  const uint16_t* bp = planes + (int64_t)bn * 16 + 8 * bchunk;   // + (plane * K / 16 + step) * N * 16
+  const uint32_t bdst = (uint32_t)__builtin_amdgcn_readfirstlane((int)(lds0 + P16_B0 + wave * 1024));
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[2][2];                                             // A register ring: [set][two 16-byte halves of the piece]
+  auto step_of = [&](int i) __attribute__((always_inline)) { return i < S ? i : S - 1; };   // steps past K re-read the last one
+#define HOTK_G6_LOAD_A(SET, I)                                  \
+  {                                                             \
+    const float* q_ = ap + 16 * step_of(I);                     \
+    g6_ld16(ra[SET][0], q_);                                    \
+    g6_ld16(ra[SET][1], q_ + 4);                                \
+  }
+#define HOTK_G6_DMA_B(I)                                                                        \
+  {                                                                                             \
+    const uint16_t* q_ = bp + (int64_t)step_of(I) * N * 16;                                     \
+    const uint32_t d_ = bdst + ((I) % 3) * STAGE16_B;                                           \
+    g6_glds16(q_, d_);                                                                          \
+    g6_glds16(q_ + PL, d_ + PLANE16_B);                                                         \
+    g6_glds16(q_ + 2 * PL, d_ + 2 * PLANE16_B);                                                 \
+  }
+#define HOTK_G6_WRITE_A(SET, I)                                                                                   \
+  {                                                                                                               \
+    g6_arrived(ra[SET][0]);                                                                                       \
+    g6_arrived(ra[SET][1]);                                                                                       \
+    const u32x4 x_ = ra[SET][0], y_ = ra[SET][1];                                                                 \
+    uint32_t h_[4], m_[4], l_[4];                                                                                 \
+    g6_split_pair(g6_u2f(x_[0]), g6_u2f(x_[1]), h_[0], m_[0], l_[0]);                                             \
+    g6_split_pair(g6_u2f(x_[2]), g6_u2f(x_[3]), h_[1], m_[1], l_[1]);                                             \
+    g6_split_pair(g6_u2f(y_[0]), g6_u2f(y_[1]), h_[2], m_[2], l_[2]);                                             \
+    g6_split_pair(g6_u2f(y_[2]), g6_u2f(y_[3]), h_[3], m_[3], l_[3]);                                             \
+    unsigned char* w_ = lds + P16_A0 + ((I) & 1) * STAGE16_A + aoff;                                              \
+    *reinterpret_cast<u32x4*>(w_) = (u32x4){h_[0], h_[1], h_[2], h_[3]};                                          \
+    *reinterpret_cast<u32x4*>(w_ + PLANE16_A) = (u32x4){m_[0], m_[1], m_[2], m_[3]};                              \
+    *reinterpret_cast<u32x4*>(w_ + 2 * PLANE16_A) = (u32x4){l_[0], l_[1], l_[2], l_[3]};                          \
+  }
+  // prologue: steps 0 and 1 requested; step 0 staged
+  HOTK_G6_LOAD_A(0, 0)
+  HOTK_G6_DMA_B(0)
+  HOTK_G6_LOAD_A(1, 1)
+  HOTK_G6_DMA_B(1)
+  g6_wait_vm<5>();                                            // A(0), B(0) landed; A(1), B(1) may be in flight
+  HOTK_G6_WRITE_A(0, 0)
+  g6_barrier_lds();
+  // iteration i: request step i + 2, multiply step i, stage A of step i + 1 (its loads were requested an iteration ago)
+  for (int i0 = 0; i0 < S; i0 += 6) {
+#pragma unroll
+    for (int u = 0; u < 6; ++u) {                             // 6 = lcm of the ring depths 2 and 3: static stage indices
+      const int i = i0 + u;
+      HOTK_G6_LOAD_A(u & 1, i + 2)
+      HOTK_G6_DMA_B(i + 2)
+      if (HOTK_G6_PROBE_PROD(i < S, i == 0))
+        g6_products16(lds + P16_A0 + (u & 1) * STAGE16_A, lds + P16_B0 + (u % 3) * STAGE16_B, wm, wn, lane, acc);
+      g6_wait_vm<5>();                                        // step i + 1 landed (A registers and B stage); step i + 2 in flight
+      HOTK_G6_WRITE_A((u + 1) & 1, i + 1)
+      g6_barrier_lds();
+    }
+  }
+#undef HOTK_G6_LOAD_A
+#undef HOTK_G6_DMA_B
+#undef HOTK_G6_WRITE_A
+  g6_drain();
+  g6_barrier_lds();                                           // the stages become the epilogue's staging image
   const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
                     (!bias || ((uintptr_t)bias & 15) == 0);
   g6_store_tile(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), bias, lds, wave,
@@ -500,11 +672,21 @@ extern "C" int hotk_gemm6_tn_supported(int64_t M, int64_t K, int64_t N) {
   return (M > 0 && K >= 4 && K % 4 == 0 && N >= 4 && N % 4 == 0 && K <= (1 << 20) && N <= (1 << 20)) ? 1 : 0;
 }
 
+namespace {
+// HOTK_G6_PIPE=1 selects the pipelined kernel (k step 16, planes [K/16][N][16]) for A/B runs; default: the two-phase one
+// (k step 32, planes [K/32][N][32]) -- they measure the same (0.93 / 0.90 ms on [254 k, 512] x [512, 512]), the simpler one
+// is kept.  One switch for hotk_gemm6_split_weight and hotk_gemm6_nn: the planes are theirs.
+bool g6_pipe() {
+  static const int v = [] { const char* e = getenv("HOTK_G6_PIPE"); return (e && e[0] == '1') ? 1 : 0; }();
+  return v != 0;
+}
+}  // namespace
+
 extern "C" int hotk_gemm6_split_weight(const float* W, int64_t ldw, int64_t K, int64_t N, int transposed, void* planes,
                                        void* stream) {
-  HOTK_CHECK_ARG(W && planes && K > 0 && N > 0 && K % 2 == 0 && ldw >= (transposed ? N : K));
+  HOTK_CHECK_ARG(W && planes && K > 0 && N > 0 && K % 32 == 0 && ldw >= (transposed ? N : K));
   hipLaunchKernelGGL(k_gemm6_split_weight, dim3(hotk_grid(N * (K / 2), 256)), dim3(256), 0, (hipStream_t)stream, W, ldw, (int)K,
-                     (int)N, transposed, (uint16_t*)planes);
+                     (int)N, transposed, (uint16_t*)planes, g6_pipe() ? 4 : 5);
   return hotk_launch_status();
 }
 
@@ -514,10 +696,18 @@ extern "C" int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, co
   if (M == 0) return HOTK_OK;
   if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
   HOTK_CHECK_ARG(A && planes && C && hotk_aligned16(A) && hotk_aligned16(planes) && (lda & 3) == 0);
-  static int attr = g6_attr(k_gemm6_nn);
-  if (attr) return attr;
   const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
   if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
+  if (g6_pipe()) {
+    static int attr16 = hipFuncSetAttribute((const void*)k_gemm6_nn16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)G6_LDS16) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
+    if (attr16) return attr16;
+    hipLaunchKernelGGL(k_gemm6_nn16, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS16, (hipStream_t)stream, A, lda,
+                       (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
+    return hotk_launch_status();
+  }
+  static int attr = g6_attr(k_gemm6_nn);
+  if (attr) return attr;
   hipLaunchKernelGGL(k_gemm6_nn, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, (hipStream_t)stream, A, lda,
                      (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
   return hotk_launch_status();
