@@ -302,7 +302,9 @@ __device__ __forceinline__ void g6_store_nn(unsigned char* lds_a, unsigned char*
 __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const float* __restrict__ A, int64_t lda,
                                                                       const uint16_t* __restrict__ planes,
                                                                       const float* __restrict__ bias, float* __restrict__ C,
-                                                                      int64_t ldc, int64_t M, int K, int N, int tiles_n) {
+                                                                      int64_t ldc, int64_t M, int K, int N, int tiles_n, int col0,
+                                                                      int ncap) {
+  // columns [col0, ncap) of the product; N = all columns of B (the stride of its planes)
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char* lds_a = lds;
   unsigned char* lds_b = lds + OPER_A;
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
   const int64_t tm = tile / tiles_n;
   const int tn = (int)(tile - tm * tiles_n);
   const int64_t m0 = tm * BM;
-  const int n0 = tn * BN;
+  const int n0 = col0 + tn * BN;
   const int64_t PL = (int64_t)N * K;            // bf16 elements per plane
   const float* ap[AP];
   const uint16_t* bp[BP];
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
   for (int q = 0; q < BP; ++q) {
     const int pi = t + q * G6_THREADS;
     int bn = n0 + g6_piece_row(pi);
-    if (bn >= N) bn = N - 1;
+    if (bn >= ncap) bn = ncap - 1;
     bp[q] = planes + (int64_t)bn * 32 + 8 * g6_piece_quarter(pi);      // + k0 * N per step: planes are [K / 32][N][32]
   }
   f32x16 acc[TM][TN];
@@ -357,12 +359,13 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     }
   }
   g6_drain();
-  const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
+  const bool full = (m0 + BM <= M) && (n0 + BN <= ncap) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
                     (!bias || ((uintptr_t)bias & 15) == 0);
-  g6_store_tile(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), bias, lds, wave,
-                lane, acc, full);
+  g6_store_tile(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), bias, lds,
+                wave, lane, acc, full);
 }
 
+#if HOTK_G6_BN == 256
 // ---- C = A . B (+ bias), pipelined form -------------------------------------------------------------------------------
 // The kernel above runs its data phase (loads -> split -> LDS writes -> barrier, ~3 us per k step) and its product phase
 // (1.3 us) one after the other: one workgroup per CU and a barrier per step keep all eight waves in phase.  Here the k step
@@ -523,6 +526,8 @@ __global__ __launch_bounds__(G6_THREADS, 1) void k_gemm6_nn16(const float* __res
                 lane, acc, full);
 }
 
+#endif  // HOTK_G6_BN == 256
+
 // ---- P[s] = A[rows of slab s]^T . G[rows of slab s] -------------------------------------------------------------------
 // Both operands are read row-major and must enter the MFMA with the ROW index as its k: the LDS planes are [k or n][32
 // rows], written as packed row PAIRS: thread (row pair mp = t & 15, column group cg = t >> 4) loads 4 consecutive columns
@@ -664,6 +669,25 @@ int g6_attr(F f) {
 
 }  // namespace
 
+#ifdef HOTK_G6_VARIANT
+// A second build of this file (csrc/gemm6_n128.hip: 256 x 128 tiles) exports ONE entry point: columns [col0, ncap) of
+// C = A . B for the column tail that would leave a 256-wide tile mostly empty.  Called by hotk_gemm6_nn below.
+#define HOTK_G6_CAT2(a, b) a##b
+#define HOTK_G6_CAT(a, b) HOTK_G6_CAT2(a, b)
+extern "C" int HOTK_G6_CAT(hotk_gemm6_nn_cols, HOTK_G6_VARIANT)(const float* A, int64_t lda, const void* planes, const float* bias,
+                                                                 float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
+                                                                 int64_t col0, int64_t ncap, void* stream) {
+  static int attr = g6_attr(k_gemm6_nn);
+  if (attr) return attr;
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (ncap - col0 + BN - 1) / BN;
+  if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
+  hipLaunchKernelGGL(k_gemm6_nn, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, (hipStream_t)stream, A, lda,
+                     (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap);
+  return hotk_launch_status();
+}
+#else
+extern "C" int hotk_gemm6_nn_cols_n128(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
+                                       int64_t M, int64_t K, int64_t N, int64_t col0, int64_t ncap, void* stream);
 extern "C" int hotk_gemm6_nn_supported(int64_t M, int64_t K, int64_t N) {
   return (M > 0 && K >= 32 && K % 32 == 0 && N >= 1 && K <= (1 << 20) && N <= (1 << 20) && M < ((int64_t)1 << 40)) ? 1 : 0;
 }
@@ -696,7 +720,16 @@ extern "C" int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, co
   if (M == 0) return HOTK_OK;
   if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
   HOTK_CHECK_ARG(A && planes && C && hotk_aligned16(A) && hotk_aligned16(planes) && (lda & 3) == 0);
-  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  // a column tail of at most 128 goes to the 256 x 128 build of the kernel (N = 320: one 256-wide and one 128-wide tile
+  // instead of two 256-wide ones, the second three quarters empty)
+  const int64_t tail = N % BN;
+  const bool split_tail = !g6_pipe() && tail > 0 && tail <= 128;
+  const int64_t nwide = split_tail ? N - tail : N;
+  if (split_tail) {
+    const int rc = hotk_gemm6_nn_cols_n128(A, lda, planes, bias, C, ldc, M, K, N, nwide, N, stream);
+    if (rc || nwide == 0) return rc;
+  }
+  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (nwide + BN - 1) / BN;
   if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
   if (g6_pipe()) {
     static int attr16 = hipFuncSetAttribute((const void*)k_gemm6_nn16, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -709,7 +742,7 @@ extern "C" int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, co
   static int attr = g6_attr(k_gemm6_nn);
   if (attr) return attr;
   hipLaunchKernelGGL(k_gemm6_nn, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, (hipStream_t)stream, A, lda,
-                     (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
+                     (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n, 0, (int)nwide);
   return hotk_launch_status();
 }
 
@@ -736,3 +769,4 @@ extern "C" int hotk_gemm6_tn(const float* A, int64_t lda, const float* G, int64_
                      partial, M, (int)K, (int)N, tiles_k, tiles_n, rps);
   return hotk_launch_status();
 }
+#endif  // HOTK_G6_VARIANT

@@ -666,7 +666,8 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows -- and
     # those column sums are one more row of the node-level weight gradient: [xd | 1]^T . dyn (no pass of their own)
     db_diag = db_off = None
-    ones_row = want_dw and (has_b[0] or has_b[1])
+    # (not when the node-level weight gradient runs on the tiled GEMM: a 257th row would cost it a whole second row of tiles)
+    ones_row = want_dw and (has_b[0] or has_b[1]) and not wgrad6_ok(xd, dyn)
     if not ones_row:
         db_diag = dyn[:, 0:C].sum(0) if has_b[1] else None
         db_off = dyn[:, C:2 * C].sum(0) if has_b[0] else None

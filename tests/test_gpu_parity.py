@@ -967,7 +967,7 @@ def test_layernorm_rows_with_mask_vs_fp64(D):
             assert rel_err(ln.weight.grad.cpu(), wd.grad.cpu()) < 2 * TOL and rel_err(ln.bias.grad.cpu(), bd.grad.cpu()) < 2 * TOL
 
 
-@pytest.mark.parametrize('M,K,N', [(20000, 512, 512), (16400 + 77, 256, 320), (33333, 320, 256), (16384, 128, 96), (40001, 1280, 512)])
+@pytest.mark.parametrize('M,K,N', [(20000, 512, 512), (16400 + 77, 256, 320), (33333, 320, 256), (16384, 128, 96), (40001, 1280, 512), (17001, 256, 864)])
 def test_gemm6_products_vs_fp64(M, K, N):
     """csrc/gemm6.hip: the tall wide projections as six bf16 MFMAs per product on exact three-way splits -- fp32-exact.
     C = A W (+ bias), C = A W^T, and the weight gradient A^T G, against float64; row counts that are not a multiple of the
