@@ -24,7 +24,15 @@
 #include "common.h"
 #include <cstdlib>
 
+// (kernels of the two builds of this file -- see csrc/gemm6_n128.hip -- must not share their symbol names: template
+// instantiations are merged across translation units even inside unnamed namespaces)
+#ifdef HOTK_G6_VARIANT
+#define HOTK_G6_NS g6_tail
+#else
+#define HOTK_G6_NS g6_wide
+#endif
 namespace {
+namespace HOTK_G6_NS {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -155,18 +163,46 @@ __device__ __forceinline__ void g6_products(const unsigned char* lds_a, const un
 // 256-byte row runs in straight-line code; tiles that cross the matrix edge store element by element under their guards
 // (one row tile and one column tile of a product at most).
 constexpr int G6_ST = 32 * TN + 4;   // floats per staged row
+// Row map (RM): the tile's rows are entries row0 .. of the ascending list `rows` [Mc] of the rows of C [Mall, .] that carry
+// data (the others are padding).  The lane that stores listed row i also writes zeros to the padding rows between it and
+// the next listed row (the first one: and before it; the last one: up to Mall), so that C leaves fully written.
+struct RowMap { const int32_t* rows; int64_t Mc, Mall; };
+__device__ __forceinline__ int64_t g6_next_row(const RowMap& rm, int64_t i) { return i + 1 < rm.Mc ? rm.rows[i + 1] : rm.Mall; }
+// (nxt = g6_next_row(rm, i), fetched by the caller together with its other list reads: one round trip, not one per row)
+template <class V>
+__device__ __forceinline__ void g6_zero_gap(float* __restrict__ C, int64_t ldc, int col, int64_t i, int64_t r, int64_t nxt) {
+  V z;
+  __builtin_memset(&z, 0, sizeof(V));
+  for (int64_t g = r + 1; g < nxt; ++g) *reinterpret_cast<V*>(C + g * ldc + col) = z;
+  if (i == 0)
+    for (int64_t g = 0; g < r; ++g) *reinterpret_cast<V*>(C + g * ldc + col) = z;
+}
+template <bool RM = false>
 __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc, int64_t row0, int64_t n_rows, int col0,
                                               int n_cols, const float* __restrict__ bias, unsigned char* lds, int wave, int lane,
-                                              const f32x16 (&acc)[TM][TN], bool full) {
+                                              const f32x16 (&acc)[TM][TN], bool full, const RowMap rm = RowMap{nullptr, 0, 0}) {
   const int cl = lane & 31, rh = 4 * (lane >> 5);
-  if (full) {
+  // `full` here: 16-byte pieces are possible (alignment of C, ldc, bias: the caller's check).  Rows past n_rows and
+  // 4-column pieces past n_cols are skipped lane by lane, so edge tiles take this path too when n_cols % 4 == 0.
+  if (full && (n_cols >= 32 * TN || (n_cols & 3) == 0) && n_rows > 0 && n_cols > 0) {
     static_assert(TN == 2, "16 lanes x 16 bytes span the staged row");
     float* st = reinterpret_cast<float*>(lds) + wave * (32 * G6_ST);
     const int row = lane >> 4, c4 = lane & 15;
+    const bool col_in = 4 * c4 < n_cols;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias) b4 = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
+    if (bias && col_in) b4 = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+      int64_t dst[8], nxt[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int64_t ti = 32 * i + 4 * q + row;      // row of the wave's tile
+        dst[q] = row0 + (ti < n_rows ? ti : n_rows - 1);
+        if (RM) {
+          nxt[q] = g6_next_row(rm, dst[q]);
+          dst[q] = rm.rows[dst[q]];
+        }
+      }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -177,9 +213,11 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
+        if (!col_in || 32 * i + 4 * q + row >= n_rows) continue;
         float4 v = *reinterpret_cast<const float4*>(st + (4 * q + row) * G6_ST + 4 * c4);
         v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        *reinterpret_cast<float4*>(C + (row0 + 32 * i + 4 * q + row) * ldc + col0 + 4 * c4) = v;
+        *reinterpret_cast<float4*>(C + dst[q] * ldc + col0 + 4 * c4) = v;
+        if (RM) g6_zero_gap<float4>(C, ldc, col0 + 4 * c4, row0 + 32 * i + 4 * q + row, dst[q], nxt[q]);
       }
     }
     return;
@@ -194,7 +232,11 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t rr = 32 * i + rh + (r & 3) + 8 * (r >> 2);
-        if (rr < n_rows) C[(row0 + rr) * ldc + col0 + n] = acc[i][j][r] + b;
+        if (rr < n_rows) {
+          const int64_t dst = RM ? (int64_t)rm.rows[row0 + rr] : row0 + rr;
+          C[dst * ldc + col0 + n] = acc[i][j][r] + b;
+          if (RM) g6_zero_gap<float>(C, ldc, col0 + n, row0 + rr, dst, g6_next_row(rm, row0 + rr));
+        }
       }
   }
 }
@@ -299,12 +341,14 @@ __device__ __forceinline__ void g6_store_nn(unsigned char* lds_a, unsigned char*
   }
 }
 
+template <bool RM>
 __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const float* __restrict__ A, int64_t lda,
                                                                       const uint16_t* __restrict__ planes,
                                                                       const float* __restrict__ bias, float* __restrict__ C,
                                                                       int64_t ldc, int64_t M, int K, int N, int tiles_n, int col0,
-                                                                      int ncap) {
-  // columns [col0, ncap) of the product; N = all columns of B (the stride of its planes)
+                                                                      int ncap, RowMap rm) {
+  // columns [col0, ncap) of the product; N = all columns of B (the stride of its planes).  RM: M = number of LISTED rows,
+  // tile row i = row rm.rows[i] of A and of C (padding rows of C: zeros, see g6_zero_gap)
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char* lds_a = lds;
   unsigned char* lds_b = lds + OPER_A;
@@ -324,6 +368,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     const int pi = t + q * G6_THREADS;
     int64_t arow = m0 + g6_piece_row(pi);
     if (arow >= M) arow = M - 1;
+    if (RM) arow = rm.rows[arow];
     ap[q] = A + arow * lda + 8 * g6_piece_quarter(pi);
   }
 #pragma unroll
@@ -359,10 +404,9 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     }
   }
   g6_drain();
-  const bool full = (m0 + BM <= M) && (n0 + BN <= ncap) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
-                    (!bias || ((uintptr_t)bias & 15) == 0);
-  g6_store_tile(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), bias, lds,
-                wave, lane, acc, full);
+  const bool full = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
+  g6_store_tile<RM>(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), bias, lds,
+                    wave, lane, acc, full, rm);
 }
 
 #if HOTK_G6_BN == 256
@@ -557,12 +601,12 @@ __device__ __forceinline__ void g6_store_t(unsigned char* oper, int plane, int t
   }
 }
 
-// rows `row`, `row + 1` of the step (addresses clamped into the slab)
+// rows rw[0], rw[1] of the operands: the thread's row pair of a step
 __device__ __forceinline__ void g6_load_tn(const float* __restrict__ A, int64_t lda, const float* __restrict__ G, int64_t ldg,
-                                           int64_t row, int64_t r1, const int (&ka)[TPA], const int (&na)[TPG], TRaw& raw) {
+                                           const int64_t (&rw)[2], const int (&ka)[TPA], const int (&na)[TPG], TRaw& raw) {
 #pragma unroll
   for (int w = 0; w < 2; ++w) {
-    const int64_t rc = row + w < r1 ? row + w : r1 - 1;
+    const int64_t rc = rw[w];
 #pragma unroll
     for (int pass = 0; pass < TPA; ++pass) g6_ld16(raw.a[pass][w], A + rc * lda + ka[pass]);
 #pragma unroll
@@ -581,10 +625,25 @@ __device__ __forceinline__ void g6_wait_tn(TRaw& raw) {
   }
 }
 
+// rows `row`, `row + 1` of a step, clamped into the slab [., r1); RM: entries of the row list
+template <bool RM>
+__device__ __forceinline__ void g6_rows_tn(int64_t row, int64_t r1, const int32_t* __restrict__ rows, int64_t (&rw)[2]) {
+#pragma unroll
+  for (int w = 0; w < 2; ++w) {
+    rw[w] = row + w < r1 ? row + w : r1 - 1;
+    if (RM) rw[w] = rows[rw[w]];
+  }
+}
+
+// RM: M = number of LISTED rows, the sum runs over rows rows[0 .. M) of A and G (the list is read with ordinary loads
+// next to the hand-counted ones: sound with one step in flight, where every wait is a wait for everything)
+static_assert(DEPTH == 1, "row lists: see above");
+template <bool RM>
 __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ G, int64_t ldg,
                                                                       float* __restrict__ partial, int64_t M, int K, int N,
-                                                                      int tiles_k, int tiles_n, int64_t rows_per_slab) {
+                                                                      int tiles_k, int tiles_n, int64_t rows_per_slab,
+                                                                      const int32_t* __restrict__ rows) {
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char* lds_a = lds;
   unsigned char* lds_b = lds + OPER_A;
@@ -621,24 +680,31 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const floa
   // DEPTH 32-row steps in flight in registers, as in k_gemm6_nn; steps past the slab re-read its last row and enter as zeros
   TRaw ring[DEPTH];
 #pragma unroll
-  for (int d = 0; d < DEPTH; ++d) g6_load_tn(A, lda, G, ldg, r0 + d * BK + 2 * mp, r1, ka, na, ring[d]);
+  for (int d = 0; d < DEPTH; ++d) {
+    int64_t rw[2];
+    g6_rows_tn<RM>(r0 + d * BK + 2 * mp, r1, rows, rw);
+    g6_load_tn(A, lda, G, ldg, rw, ka, na, ring[d]);
+  }
   for (int64_t m = r0; m < r1; m += DEPTH * BK) {
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       const int64_t mm = m + d * BK;
       g6_wait_tn(ring[d]);
+      // (RM: the list entries of the next loads are fetched here, a split + LDS write + barrier ahead of their use)
+      int64_t rw[2];
+      g6_rows_tn<RM>(mm + DEPTH * BK + 2 * mp, r1, rows, rw);
       const bool in0 = mm + 2 * mp < r1, in1 = mm + 2 * mp + 1 < r1;
       g6_store_t<TPA>(lds_a, PLANE_A, t, ring[d].a, in0, in1);
       g6_store_t<TPG>(lds_b, PLANE_B, t, ring[d].g, in0, in1);
       __syncthreads();
-      g6_load_tn(A, lda, G, ldg, mm + DEPTH * BK + 2 * mp, r1, ka, na, ring[d]);
+      g6_load_tn(A, lda, G, ldg, rw, ka, na, ring[d]);
       if (mm < r1) g6_products(lds_a, lds_b, wm, wn, lane, acc);
       __syncthreads();
     }
   }
   g6_drain();
   float* P = partial + slab * (int64_t)K * N;
-  const bool full = (k0 + BM <= K) && (n0 + BN <= N) && (N & 3) == 0 && ((uintptr_t)partial & 15) == 0;
+  const bool full = (N & 3) == 0 && ((uintptr_t)partial & 15) == 0;
   g6_store_tile(P, N, k0 + 32 * TM * wm, K - (k0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), nullptr, lds, wave,
                 lane, acc, full);
 }
@@ -667,6 +733,30 @@ int g6_attr(F f) {
                                                                                                                     : HOTK_ELAUNCH;
 }
 
+// columns [col0, ncap) of C = A . B on this build's tiles; rows: see hotk_gemm6_nn_rows
+int g6_launch_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
+                 int64_t N, int64_t col0, int64_t ncap, const int32_t* rows, int64_t Mc, hipStream_t st) {
+  const int64_t Mt = rows ? Mc : M;
+  const int64_t tiles_m = (Mt + BM - 1) / BM, tiles_n = (ncap - col0 + BN - 1) / BN;
+  if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
+  const dim3 grid((unsigned)(tiles_m * tiles_n));
+  const RowMap rm{rows, Mc, M};
+  if (rows) {
+    static int attr = g6_attr(k_gemm6_nn<true>);
+    if (attr) return attr;
+    hipLaunchKernelGGL(k_gemm6_nn<true>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, (const uint16_t*)planes, bias, C, ldc, Mt,
+                       (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap, rm);
+  } else {
+    static int attr = g6_attr(k_gemm6_nn<false>);
+    if (attr) return attr;
+    hipLaunchKernelGGL(k_gemm6_nn<false>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, (const uint16_t*)planes, bias, C, ldc, Mt,
+                       (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap, rm);
+  }
+  return hotk_launch_status();
+}
+
+}  // namespace HOTK_G6_NS
+using namespace HOTK_G6_NS;
 }  // namespace
 
 #ifdef HOTK_G6_VARIANT
@@ -676,18 +766,14 @@ int g6_attr(F f) {
 #define HOTK_G6_CAT(a, b) HOTK_G6_CAT2(a, b)
 extern "C" int HOTK_G6_CAT(hotk_gemm6_nn_cols, HOTK_G6_VARIANT)(const float* A, int64_t lda, const void* planes, const float* bias,
                                                                  float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
-                                                                 int64_t col0, int64_t ncap, void* stream) {
-  static int attr = g6_attr(k_gemm6_nn);
-  if (attr) return attr;
-  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (ncap - col0 + BN - 1) / BN;
-  if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
-  hipLaunchKernelGGL(k_gemm6_nn, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, (hipStream_t)stream, A, lda,
-                     (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap);
-  return hotk_launch_status();
+                                                                 int64_t col0, int64_t ncap, const int32_t* rows, int64_t Mc,
+                                                                 void* stream) {
+  return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, col0, ncap, rows, Mc, (hipStream_t)stream);
 }
 #else
 extern "C" int hotk_gemm6_nn_cols_n128(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
-                                       int64_t M, int64_t K, int64_t N, int64_t col0, int64_t ncap, void* stream);
+                                       int64_t M, int64_t K, int64_t N, int64_t col0, int64_t ncap, const int32_t* rows,
+                                       int64_t Mc, void* stream);
 extern "C" int hotk_gemm6_nn_supported(int64_t M, int64_t K, int64_t N) {
   return (M > 0 && K >= 32 && K % 32 == 0 && N >= 1 && K <= (1 << 20) && N <= (1 << 20) && M < ((int64_t)1 << 40)) ? 1 : 0;
 }
@@ -704,6 +790,64 @@ bool g6_pipe() {
   static const int v = [] { const char* e = getenv("HOTK_G6_PIPE"); return (e && e[0] == '1') ? 1 : 0; }();
   return v != 0;
 }
+
+// rows == nullptr: all M rows.  Otherwise the Mc listed rows (ascending, each < M); the other rows of C are zeroed.
+int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
+          int64_t N, const int32_t* rows, int64_t Mc, hipStream_t st) {
+  HOTK_CHECK_ARG(M >= 0 && lda >= K && ldc >= N && (!rows || (Mc >= 0 && Mc <= M && M <= 0x7fffffffll)));
+  if (M == 0) return HOTK_OK;
+  if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
+  HOTK_CHECK_ARG(A && planes && C && hotk_aligned16(A) && hotk_aligned16(planes) && (lda & 3) == 0);
+  if (rows && Mc == 0)
+    return hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st) == hipSuccess
+               ? HOTK_OK : HOTK_ELAUNCH;
+  // a column tail of at most 128 goes to the 256 x 128 build of the kernel (N = 320: one 256-wide and one 128-wide tile
+  // instead of two 256-wide ones, the second three quarters empty)
+  const int64_t tail = N % BN;
+  const bool pipe = g6_pipe() && !rows;
+  const bool split_tail = !pipe && tail > 0 && tail <= 128;
+  const int64_t nwide = split_tail ? N - tail : N;
+  if (split_tail) {
+    const int rc = hotk_gemm6_nn_cols_n128(A, lda, planes, bias, C, ldc, M, K, N, nwide, N, rows, Mc, st);
+    if (rc || nwide == 0) return rc;
+  }
+  if (pipe) {
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (nwide + BN - 1) / BN;
+    if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
+    static int attr16 = hipFuncSetAttribute((const void*)k_gemm6_nn16, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)G6_LDS16) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
+    if (attr16) return attr16;
+    hipLaunchKernelGGL(k_gemm6_nn16, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS16, st, A, lda,
+                       (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
+    return hotk_launch_status();
+  }
+  return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, 0, nwide, rows, Mc, st);
+}
+
+int g6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K, int64_t N,
+          const int32_t* rows, int64_t Mc, hipStream_t st) {
+  HOTK_CHECK_ARG(M >= 0 && lda >= K && ldg >= N && partial && (!rows || (Mc >= 0 && Mc <= M && M <= 0x7fffffffll)));
+  const int64_t Ms = rows ? Mc : M;      // rows summed over
+  if (Ms == 0) return hipMemsetAsync(partial, 0, (size_t)K * N * sizeof(float), st) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
+  if (!hotk_gemm6_tn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
+  HOTK_CHECK_ARG(A && G && hotk_aligned16(A) && hotk_aligned16(G) && ((lda | ldg) & 3) == 0);
+  int64_t rps;
+  const int slabs = g6_slabs(Ms, K, N, &rps);
+  const int tiles_k = (int)((K + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
+  const dim3 grid((unsigned)((int64_t)slabs * tiles_k * tiles_n));
+  if (rows) {
+    static int attr = g6_attr(k_gemm6_tn<true>);
+    if (attr) return attr;
+    hipLaunchKernelGGL(k_gemm6_tn<true>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg, partial, Ms, (int)K, (int)N, tiles_k,
+                       tiles_n, rps, rows);
+  } else {
+    static int attr = g6_attr(k_gemm6_tn<false>);
+    if (attr) return attr;
+    hipLaunchKernelGGL(k_gemm6_tn<false>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg, partial, Ms, (int)K, (int)N,
+                       tiles_k, tiles_n, rps, rows);
+  }
+  return hotk_launch_status();
+}
 }  // namespace
 
 extern "C" int hotk_gemm6_split_weight(const float* W, int64_t ldw, int64_t K, int64_t N, int transposed, void* planes,
@@ -716,34 +860,14 @@ extern "C" int hotk_gemm6_split_weight(const float* W, int64_t ldw, int64_t K, i
 
 extern "C" int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
                              int64_t M, int64_t K, int64_t N, void* stream) {
-  HOTK_CHECK_ARG(M >= 0 && lda >= K && ldc >= N);
-  if (M == 0) return HOTK_OK;
-  if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
-  HOTK_CHECK_ARG(A && planes && C && hotk_aligned16(A) && hotk_aligned16(planes) && (lda & 3) == 0);
-  // a column tail of at most 128 goes to the 256 x 128 build of the kernel (N = 320: one 256-wide and one 128-wide tile
-  // instead of two 256-wide ones, the second three quarters empty)
-  const int64_t tail = N % BN;
-  const bool split_tail = !g6_pipe() && tail > 0 && tail <= 128;
-  const int64_t nwide = split_tail ? N - tail : N;
-  if (split_tail) {
-    const int rc = hotk_gemm6_nn_cols_n128(A, lda, planes, bias, C, ldc, M, K, N, nwide, N, stream);
-    if (rc || nwide == 0) return rc;
-  }
-  const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (nwide + BN - 1) / BN;
-  if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
-  if (g6_pipe()) {
-    static int attr16 = hipFuncSetAttribute((const void*)k_gemm6_nn16, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)G6_LDS16) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
-    if (attr16) return attr16;
-    hipLaunchKernelGGL(k_gemm6_nn16, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS16, (hipStream_t)stream, A, lda,
-                       (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
-    return hotk_launch_status();
-  }
-  static int attr = g6_attr(k_gemm6_nn);
-  if (attr) return attr;
-  hipLaunchKernelGGL(k_gemm6_nn, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, (hipStream_t)stream, A, lda,
-                     (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n, 0, (int)nwide);
-  return hotk_launch_status();
+  return g6_nn(A, lda, planes, bias, C, ldc, M, K, N, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int hotk_gemm6_nn_rows(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
+                                  int64_t M, int64_t K, int64_t N, const int32_t* rows, int64_t n_rows, void* stream) {
+  HOTK_CHECK_ARG(rows || n_rows == 0);
+  if (!rows) return hotk_gemm6_nn(A, lda, planes, bias, C, ldc, M, K, N, stream);
+  return g6_nn(A, lda, planes, bias, C, ldc, M, K, N, rows, n_rows, (hipStream_t)stream);
 }
 
 extern "C" int hotk_gemm6_tn_partials(int64_t M, int64_t K, int64_t N, int64_t* n_partials) {
@@ -755,18 +879,13 @@ extern "C" int hotk_gemm6_tn_partials(int64_t M, int64_t K, int64_t N, int64_t* 
 
 extern "C" int hotk_gemm6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K,
                              int64_t N, void* stream) {
-  HOTK_CHECK_ARG(M >= 0 && lda >= K && ldg >= N && partial);
-  hipStream_t st = (hipStream_t)stream;
-  if (M == 0) return hipMemsetAsync(partial, 0, (size_t)K * N * sizeof(float), st) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
-  if (!hotk_gemm6_tn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
-  HOTK_CHECK_ARG(A && G && hotk_aligned16(A) && hotk_aligned16(G) && ((lda | ldg) & 3) == 0);
-  static int attr = g6_attr(k_gemm6_tn);
-  if (attr) return attr;
-  int64_t rps;
-  const int slabs = g6_slabs(M, K, N, &rps);
-  const int tiles_k = (int)((K + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
-  hipLaunchKernelGGL(k_gemm6_tn, dim3((unsigned)((int64_t)slabs * tiles_k * tiles_n)), dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg,
-                     partial, M, (int)K, (int)N, tiles_k, tiles_n, rps);
-  return hotk_launch_status();
+  return g6_tn(A, lda, G, ldg, partial, M, K, N, nullptr, 0, (hipStream_t)stream);
+}
+
+extern "C" int hotk_gemm6_tn_rows(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K,
+                                  int64_t N, const int32_t* rows, int64_t n_rows, void* stream) {
+  HOTK_CHECK_ARG(rows || n_rows == 0);
+  if (!rows) return hotk_gemm6_tn(A, lda, G, ldg, partial, M, K, N, stream);
+  return g6_tn(A, lda, G, ldg, partial, M, K, N, rows, n_rows, (hipStream_t)stream);
 }
 #endif  // HOTK_G6_VARIANT

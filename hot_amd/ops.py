@@ -311,15 +311,36 @@ def mm6_ok(A, K, N):
             and K >= 128 and N >= 96)
 
 
-def mm(A, W, bias=None, trans_w=False):
+_G6_ROWS = os.environ.get('HOTK_GEMM_ROWS', '1') == '1'
+
+
+def valid_rows(plan, level):
+    """ascending int32 list of the plan's valid entry rows (level 'e') or node rows ('n') for the GEMMs that skip padding
+    rows (hotk_gemm6_nn_rows / _tn_rows); None when no row is padding.  Built once per plan."""
+    if not _G6_ROWS:
+        return None
+    key = '_valid_' + level
+    d = plan.__dict__
+    if key not in d:
+        k = plan.kind if level == 'e' else plan.nkind
+        idx = torch.nonzero(k).view(-1).to(torch.int32)
+        d[key] = None if idx.numel() == k.numel() else idx
+    return d[key]
+
+
+def mm(A, W, bias=None, trans_w=False, rows=None):
     """A[M, K] @ W[K, N] (+ bias), or A[M, K] @ W[N, K]^T with trans_w: the split-bf16 tiled GEMM for tall, wide products
-    (fp32-exact: six bf16 MFMAs per product on three-way exact splits, weight split once per call), the library otherwise"""
+    (fp32-exact: six bf16 MFMAs per product on three-way exact splits, weight split once per call), the library otherwise.
+    rows (valid_rows of the plan): the tiled GEMM computes the listed rows only and writes zeros to the others; the library
+    path computes every row (callers mask afterwards as if rows were None: see mm_masks)."""
     K = A.size(1)
     N = W.size(0) if trans_w else W.size(1)
     assert (W.size(1) if trans_w else W.size(0)) == K
     if not mm6_ok(A, K, N) or W.dtype != torch.float32:
         Wm = W.t() if trans_w else W
         return torch.addmm(bias, A, Wm) if bias is not None else A @ Wm
+    if rows is not None and rows.numel() == 0:      # (an empty list: a NULL pointer would mean "all rows" to the library)
+        return torch.zeros(A.size(0), N, dtype=torch.float32, device=A.device)
     a, lda = _row_major(A)
     M = a.size(0)
     if W.stride(1) != 1 and W.stride(0) == 1:      # a transposed VIEW of a row-major weight: read the storage as it lies
@@ -328,8 +349,17 @@ def mm(A, W, bias=None, trans_w=False):
     planes = torch.empty(3, N, K, dtype=torch.bfloat16, device=A.device)
     call('hotk_gemm6_split_weight', 10 * K * N, p(w), ldw, K, N, 0 if trans_w else 1, p(planes))
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    call('hotk_gemm6_nn', 4 * M * (K + N), p(a), lda, p(planes), p(bias), p(C), N, M, K, N)
+    if rows is None:
+        call('hotk_gemm6_nn', 4 * M * (K + N), p(a), lda, p(planes), p(bias), p(C), N, M, K, N)
+    else:
+        call('hotk_gemm6_nn_rows', 4 * rows.numel() * (K + N), p(a), lda, p(planes), p(bias), p(C), N, M, K, N, p(rows),
+             rows.numel())
     return C
+
+
+def mm_masks(A, W, rows, trans_w=False):
+    """whether mm(A, W, ., trans_w, rows) leaves the padding rows of its result zero by itself"""
+    return rows is not None and W.dtype == torch.float32 and mm6_ok(A, A.size(1), W.size(0) if trans_w else W.size(1))
 
 
 def wgrad6_ok(A, B):
@@ -341,15 +371,22 @@ def wgrad6_ok(A, B):
             and K >= 256 and N >= 256 and K * N >= 512 * 256 and K % 4 == 0 and N % 4 == 0)
 
 
-def wgrad6(A, B):
-    """A^T @ B over the rows (hotk_gemm6_tn): per-slab partial products summed in slab order (reproducible)"""
+def wgrad6(A, B, rows=None):
+    """A^T @ B over the rows (hotk_gemm6_tn): per-slab partial products summed in slab order (reproducible); rows: over the
+    listed rows only (hotk_gemm6_tn_rows)"""
+    if rows is not None and rows.numel() == 0:
+        return torch.zeros(A.size(1), B.size(1), dtype=torch.float32, device=A.device)
     a, lda = _row_major(A)
     b, ldb = _row_major(B)
     M, K, N = a.size(0), a.size(1), b.size(1)
+    Ms = M if rows is None else rows.numel()
     n = ctypes_long()
-    check(lib().hotk_gemm6_tn_partials(M, K, N, byref(n)), 'hotk_gemm6_tn_partials')
+    check(lib().hotk_gemm6_tn_partials(Ms, K, N, byref(n)), 'hotk_gemm6_tn_partials')
     part = torch.empty(n.value, K, N, dtype=torch.float32, device=A.device)
-    call('hotk_gemm6_tn', 4 * M * (K + N), p(a), lda, p(b), ldb, p(part), M, K, N)
+    if rows is None:
+        call('hotk_gemm6_tn', 4 * M * (K + N), p(a), lda, p(b), ldb, p(part), M, K, N)
+    else:
+        call('hotk_gemm6_tn_rows', 4 * Ms * (K + N), p(a), lda, p(b), ldb, p(part), M, K, N, p(rows), Ms)
     return part[0] if n.value == 1 else part.sum(0)
 
 
@@ -635,7 +672,7 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
     dev = xs.device
     xd = gather_rows(xs, plan.diag_pos, plan.Nn)                                   # [Nn, D]
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)               # [D, 3C]
-    yn = mm(xd, Wn)
+    yn = mm(xd, Wn, rows=valid_rows(plan, 'n'))
     x2 = torch.empty(plan.R, 2 * D, dtype=xs.dtype, device=dev)
     call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
     if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
@@ -644,7 +681,7 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
         call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
              p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
     else:
-        y = mm(x2, W[D:3 * D])
+        y = mm(x2, W[D:3 * D], rows=valid_rows(plan, 'e'))
         call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
              p(b_diag), n, C)
     return y, xd, x2
@@ -656,6 +693,7 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     rows (fc_v's); both are folded into hotk_basis22_pair_bwd's single pass over dx."""
     D, C = xd.size(1), W.size(1)
     dev = g.device
+    vn, ve = valid_rows(plan, 'n'), valid_rows(plan, 'e')
     if plan.Ev != plan.R:
         g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)      # padding rows of an upstream gradient may hold anything
     # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
@@ -674,12 +712,12 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
     dx = dW = None
     if want_dx:
-        dxd = mm(dyn, Wn, trans_w=True)
+        dxd = mm(dyn, Wn, trans_w=True, rows=vn)
         if dxd_extra is not None:
             dxd += dxd_extra
         # wide-input data gradient [R, C] x [C, 2D]: the thin kernel's row stream since its two-register-set form
         # (same-box A/B at 10 M rows, C = 288 -> 64: 3.08 ms against 3.46 ms for the library GEMM)
-        dx2 = thin_gemm(g, W[D:3 * D].t()) if (g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)) else mm(g, W[D:3 * D], trans_w=True)
+        dx2 = thin_gemm(g, W[D:3 * D].t()) if (g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)) else mm(g, W[D:3 * D], trans_w=True, rows=ve)
         dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
         call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
@@ -688,13 +726,13 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
             # (the ones column padded to four: rows of [xd | 1 0 0 0] stay 16-byte aligned for the tiled weight-gradient GEMM)
             one = torch.zeros(xd.size(0), 4, dtype=xd.dtype, device=dev)
             one[:, 0] = 1.
-            dWn = wgrad(torch.cat([xd, one], dim=1), dyn)
+            dWn = wgrad(torch.cat([xd, one], dim=1), dyn, vn)
             db_diag = dWn[D, 0:C] if has_b[1] else None
             db_off = dWn[D, C:2 * C] if has_b[0] else None
             dWn = dWn[:D]
         else:
-            dWn = wgrad(xd, dyn)
-        dW = torch.cat([dWn[:, 0:C], wgrad(x2, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
+            dWn = wgrad(xd, dyn, vn)
+        dW = torch.cat([dWn[:, 0:C], wgrad(x2, g, ve), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
     return dx, dW, db_off, db_diag
 
 
@@ -738,15 +776,16 @@ class Proj22(Function):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
         h2, xd, x2 = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
-        if b1 is not None and not nodes_padded:
-            h1 = mm(xd, W1, b1)      # no padding node rows: the bias rides on the GEMM, nothing to mask
+        vn, ve = valid_rows(plan, 'n'), valid_rows(plan, 'e')
+        if b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn)):
+            h1 = mm(xd, W1, b1, rows=vn)   # the bias rides on the GEMM: no padding node rows, or the GEMM leaves them zero
         else:
-            h1 = mm(xd, W1)
+            h1 = mm(xd, W1, rows=vn)
             call('hotk_bias_mask_rows', 8 * plan.Nn * h1.size(1), p(h1), h1.size(1), p(plan.nkind), p(None), p(b1), plan.Nn,
                  h1.size(1))
         xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
         wv = Wv.t()
-        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True)
+        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True, rows=ve)
         ctx.save_for_backward(xc, xd, x2, W1, W2, Wv)
         ctx.plan, ctx.xshape, ctx.nodes_padded = plan, x.shape, nodes_padded
         ctx.has_b = (b1 is not None, b2_off is not None, b2_diag is not None)
@@ -763,14 +802,16 @@ class Proj22(Function):
         if linear_bwd_ok(plan.R, D, dv2.size(1)):
             dxv, dwv, dbv = linear_bwd_fused(dv2, xc, wv)
         else:
-            dxv, dwv, dbv = mm(dv2, Wv), wgrad(xc, dv2), dv2.sum(0)
+            ve = valid_rows(plan, 'e')
+            dxv, dwv, dbv = mm(dv2, Wv, rows=ve), wgrad(xc, dv2, ve), dv2.sum(0)
         # fc_1 (node rows)
         g1 = dh1.contiguous().view(plan.Nn, -1)
         if ctx.nodes_padded:
             g1 = mask_rows(g1, plan.nkind, KEEP_VALID, 0.0)
         db1 = bias_grads(g1, plan.nkind, False, True)[1] if ctx.has_b[0] else None
-        dW1 = wgrad(xd, g1)
-        dxd1 = mm(g1, W1, trans_w=True)
+        vn = valid_rows(plan, 'n')
+        dW1 = wgrad(xd, g1, vn)
+        dxd1 = mm(g1, W1, trans_w=True, rows=vn)
         # fc_2, with the other two gradients of x folded in
         g2 = dh2.contiguous().view(plan.R, -1)
         dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv)
@@ -1035,13 +1076,14 @@ def _ptr(t):
     return 0 if t is None else t.data_ptr()
 
 
-def wgrad(A, B):
+def wgrad(A, B, rows=None):
     """A^T @ B for tall operands A [R,K], B [R,N] (a reduction over R rows into a small K x N result).
     A single library GEMM has only K*N/tile workgroups to run on, so the row dimension is split into S batches
-    (torch.bmm -> rocBLAS/hipBLASLt batched GEMM) whose partial products are summed: split-K over 256 CUs."""
+    (torch.bmm -> rocBLAS/hipBLASLt batched GEMM) whose partial products are summed: split-K over 256 CUs.
+    rows: the rows that are not padding (the tiled GEMM skips the others; they are zero in A or B either way)."""
     R = A.size(0)
     if wgrad6_ok(A, B):
-        return wgrad6(A, B)
+        return wgrad6(A, B, rows)
     if R < (1 << 16):
         return (A.t() @ B).float()
     S = 256
@@ -1194,8 +1236,9 @@ class AttnCore22(Function):
         if not padded and thin_ok(plan.R, 320, D):
             out = thin_gemm(att, w_o.t(), b_o, skip).view(*h2.shape[:-1], D)      # projection + bias + skip path in one pass
         else:
-            y = mm(att, w_o, b_o, trans_w=True)
-            if padded:
+            ve = valid_rows(plan, 'e')
+            y = mm(att, w_o, b_o, trans_w=True, rows=ve)
+            if padded and not mm_masks(att, w_o, ve, True):
                 y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
             out = y.add_(skip).view(*h2.shape[:-1], D)
         ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg, phik, kvn)
@@ -1223,14 +1266,15 @@ class AttnCore22(Function):
         d_out = d_out.contiguous().view(plan.R, D)
         padded = plan.Ev != plan.R
         dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
-        datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else mm(dy, w_o)
+        ve = valid_rows(plan, 'e')
+        datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else mm(dy, w_o, rows=ve)
         # att as saved = the (dropped-out) input of fc_o.  dW_o = dy^T . att in the weight-gradient-only mode of
         # hotk_linear_bwd_fused (x = dy, g = att): 3.65 ms against 3.41 ms for the split-K batched GEMM before that
         # kernel's loads were made unconditional, measured again after (profiles/NOTES_r01_r02.md, old section 5)
         if _DWO_FUSED and dy.dtype == torch.float32 and linear_bwd_ok(plan.R, D, 320):
             dw_o = linear_bwd_fused(att, dy.contiguous(), None)[1]
         else:
-            dw_o = wgrad(dy, att)
+            dw_o = wgrad(dy, att, ve)
         db_o = dy.sum(0)
         mu, keep, drop_p = ctx.drop
         AttnCore22._drop_apply(datt, plan, mu, keep, drop_p)

@@ -301,6 +301,15 @@ int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, const float* 
 int hotk_gemm6_tn_partials(int64_t M, int64_t K, int64_t N, int64_t* n_partials);
 int hotk_gemm6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K, int64_t N,
                   void* stream);
+/* The same products over a LIST of rows: rows[0 .. n_rows) ascending, each < M -- the valid rows of the reference's padded
+ * [B, Emax, D] / [B, Nmax, D] batch (models/sparse/linear.py:46-48 multiplies the padding rows too and apply_mask(0)
+ * zeroes them afterwards, :345-346; ~30 % of a PCQM4M batch's rows).  _nn_rows: C[rows[i]] = A[rows[i]] . B + bias, every
+ * other row of C[M, N] is written as zeros (the mask is part of the product);  _tn_rows: the sum runs over the listed
+ * rows only, partial blocks: hotk_gemm6_tn_partials(n_rows, K, N).  rows == NULL: all rows, as the calls above. */
+int hotk_gemm6_nn_rows(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M,
+                       int64_t K, int64_t N, const int32_t* rows, int64_t n_rows, void* stream);
+int hotk_gemm6_tn_rows(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K, int64_t N,
+                       const int32_t* rows, int64_t n_rows, void* stream);
 
 /* LayerNorm over the rows of a batch with the padding mask folded in: y[r] = (keep >> kind[r]) & 1 ? LN(x[r]) * gamma +
  * beta : 0 (kind NULL: every row), stats[r] = {mean, rstd} for the backward.  replaces Apply(nn.LayerNorm) + batch_like's

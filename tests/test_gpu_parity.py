@@ -1001,3 +1001,57 @@ def test_gemm6_products_vs_fp64(M, K, N):
     assert torch.equal(dW, ops.wgrad6(A, G))                # slabs are added in a fixed order
     assert ops.wgrad6_ok(A, G) == (K >= 256 and N >= 256 and K * N >= 512 * 256)
     assert rel_err(ops.wgrad(A, G).cpu(), refw.cpu()) < TOL          # (the library fallback for the other shapes: its own fp32 error)
+
+
+@pytest.mark.parametrize('M,K,N,keep', [(20000, 512, 512, 0.7), (16400 + 77, 256, 320, 0.7), (16384, 128, 96, 0.5),
+                                        (40001, 1280, 512, 0.97), (17001, 256, 864, 0.02), (16500, 256, 256, 0.0)])
+def test_gemm6_over_listed_rows(M, K, N, keep):
+    """hotk_gemm6_nn_rows / _tn_rows: the products over the valid rows of a padded batch only (the reference multiplies
+    the padding rows too and zeroes them afterwards, models/sparse/linear.py:46-48,345-346).  C = mask(A W + b) with EXACT
+    zeros on every row that is not listed -- also the rows before the first and after the last listed one, and when A
+    holds non-finite values there -- and the weight gradient over the listed rows, against float64.  Row lists: per-graph
+    valid prefixes as in the sparse batch (runs of valid rows followed by runs of padding), nearly full, nearly empty, empty."""
+    _lib, ops, *_ = _product()
+    g = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=g)
+    # runs: graph b owns rows [62 b, 62 b + 62), its first n_b rows are valid
+    per = 62
+    nb = (M + per - 1) // per
+    nvalid = (torch.rand(nb, generator=g) < keep).long() * torch.randint(1, per + 1, (nb,), generator=g) if keep < 0.9 else \
+        torch.randint(per - 3, per + 1, (nb,), generator=g)
+    if keep == 0.0:
+        nvalid.zero_()
+    nvalid[0] = 0 if keep < 0.9 else nvalid[0]               # the batch starts with padding rows
+    pos = torch.arange(M)
+    mask = (pos % per) < nvalid[pos // per]
+    if keep == 0.02:
+        mask[-5:] = False
+    rows = torch.nonzero(mask).view(-1).to(torch.int32).to(DEV)
+    A[~mask] = float('nan')                                  # padding rows must not be read into the result
+    A = A.to(DEV)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+    b = torch.randn(N, generator=g).to(DEV)
+    G = torch.randn(M, N, generator=g).to(DEV)
+    _lib.timing_begin(None)
+    y = ops.mm(A, W, b, rows=rows)
+    yt = ops.mm(A, W.t().contiguous(), None, trans_w=True, rows=rows)
+    ran = _lib.timing_end()
+    assert (ran['hotk_gemm6_nn_rows'][1] == 2 if rows.numel() else not ran) and ops.mm_masks(A, W, rows)
+    md = mask.to(DEV)
+    Az = torch.where(md[:, None], A, torch.zeros_like(A))
+    ref = Az.double() @ W.double()
+    assert float(y[~md].abs().max() if (~md).any() else 0.) == 0.0 and not torch.isnan(y).any()
+    assert float(yt[~md].abs().max() if (~md).any() else 0.) == 0.0 and not torch.isnan(yt).any()
+    if rows.numel():
+        assert rel_err(y[md].cpu(), (ref + b.double())[md].cpu()) < 2e-6
+        assert rel_err(yt[md].cpu(), ref[md].cpu()) < 2e-6
+        # the listed rows are the same numbers as the all-rows product on a zero-padded A
+        assert torch.equal(yt[md], ops.mm(Az, W)[md])
+    if ops.wgrad6_ok(A, G):
+        _lib.timing_begin(None)
+        dW = ops.wgrad6(A, G, rows)
+        assert ('hotk_gemm6_tn_rows' in _lib.timing_end()) == (rows.numel() > 0)
+        refw = Az.double().t() @ G.double()
+        assert not torch.isnan(dW).any()
+        assert rel_err(dW.cpu(), refw.cpu()) < 2e-6 if rows.numel() else float(dW.abs().max()) == 0.0
+        assert torch.equal(dW, ops.wgrad6(A, G, rows))
