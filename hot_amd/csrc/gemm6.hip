@@ -714,10 +714,15 @@ constexpr size_t G6_STAGE = (size_t)WM * WN * 32 * G6_ST * sizeof(float);
 constexpr size_t G6_LDS = (size_t)(OPER_A + OPER_B) > G6_STAGE ? (size_t)(OPER_A + OPER_B) : G6_STAGE;
 static_assert(HOTK_G6_WGS * G6_LDS <= 160 * 1024, "LDS of the workgroups of a CU");
 
+#ifndef HOTK_G6_TN_WGS
+#define HOTK_G6_TN_WGS 256
+#endif
 int g6_slabs(int64_t M, int64_t K, int64_t N, int64_t* rows_per_slab) {
   const int64_t tiles = ((K + BM - 1) / BM) * ((N + BN - 1) / BN);
-  // enough workgroups for two per CU, slabs of at least 1 024 rows (a multiple of the 32-row step)
-  int64_t s = (2 * 256 + tiles - 1) / tiles;
+  // one round of workgroups over the 256 CUs (one is resident per CU; a second round that is not full costs a whole
+  // round, and every slab costs a K x N partial block written and read again), slabs of at least 1 024 rows (a multiple
+  // of the 32-row step)
+  int64_t s = HOTK_G6_TN_WGS / tiles;
   const int64_t max_s = (M + 1023) / 1024;
   if (s > max_s) s = max_s;
   if (s < 1) s = 1;

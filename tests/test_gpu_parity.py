@@ -1047,7 +1047,7 @@ def test_gemm6_over_listed_rows(M, K, N, keep):
         assert rel_err(yt[md].cpu(), ref[md].cpu()) < 2e-6
         # the listed rows are the same numbers as the all-rows product on a zero-padded A
         assert torch.equal(yt[md], ops.mm(Az, W)[md])
-    if ops.wgrad6_ok(A, G):
+    if ops.wgrad6_ok(A, G, rows):
         _lib.timing_begin(None)
         dW = ops.wgrad6(A, G, rows)
         assert ('hotk_gemm6_tn_rows' in _lib.timing_end()) == (rows.numel() > 0)
