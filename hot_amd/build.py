@@ -60,5 +60,13 @@ def build(force=False, verbose=True, extra_flags=(), out=OUT):
     return out
 
 
+def assembly(src, out, extra_flags=()):
+    """device assembly of one source, compiled with the library's own flags (for tests/asm_hazards.py)"""
+    hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+    subprocess.check_call([hipcc] + FLAGS + list(extra_flags) + ['-S', '--cuda-device-only', '-o', out, src],
+                          stderr=subprocess.DEVNULL)
+    return out
+
+
 if __name__ == '__main__':
     build(force='--force' in sys.argv)

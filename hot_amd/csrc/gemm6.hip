@@ -80,6 +80,10 @@ __device__ __forceinline__ void g6_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory");
 }
 __device__ __forceinline__ void g6_arrived(u32x4& v) { asm volatile("" : "+v"(v) : : "memory"); }
+// After the loop: loads of steps past the end are still landing.  The wait alone does not keep the compiler from giving
+// the ring's registers to something else BEFORE it (register arithmetic may move above a volatile asm): follow it with
+// g6_arrived() on every register of the ring, which keeps them allocated up to this point.  scratch/check_async_regs.py
+// scans the assembly for violations of this discipline.
 __device__ __forceinline__ void g6_drain() { asm volatile("s_waitcnt vmcnt(0)" : : : "memory"); }
 
 // timing probes (A/B builds only; results are wrong with either): NOLOAD re-reads the first k step (cache hits: no memory
@@ -404,6 +408,8 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     }
   }
   g6_drain();
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) g6_wait_nn(ring[d]);      // the ring's registers stay allocated until the drain (see g6_drain)
   const bool full = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
   g6_store_tile<RM>(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), bias, lds,
                     wave, lane, acc, full, rm);
@@ -471,6 +477,11 @@ __device__ __forceinline__ void g6_products16(const unsigned char* la, const uns
 #undef HOTK_G6_STEP
 }
 
+// PP ("ping-pong"): the two wave groups (rows 0..127 / 128..255 of the tile: one wave of each per SIMD) take turns --
+// while one multiplies step i, the other requests step i + 2 and stages its share of step i + 1 -- so that one wave's
+// fragment reads, splits and LDS writes run under the other's MFMAs instead of both waves of a SIMD doing the same
+// thing at the same time.  Two barriers per step; every wave passes the same number of them.
+template <bool PP>
 __global__ __launch_bounds__(G6_THREADS, 1) void k_gemm6_nn16(const float* __restrict__ A, int64_t lda,
                                                               const uint16_t* __restrict__ planes, const float* __restrict__ bias,
                                                               float* __restrict__ C, int64_t ldc, int64_t M, int K, int N,
@@ -514,15 +525,15 @@ __global__ __launch_bounds__(G6_THREADS, 1) void k_gemm6_nn16(const float* __res
     g6_ld16(ra[SET][0], q_);                                    \
     g6_ld16(ra[SET][1], q_ + 4);                                \
   }
-#define HOTK_G6_DMA_B(I)                                                                        \
+#define HOTK_G6_DMA_B(I, STAGE)                                                                 \
   {                                                                                             \
     const uint16_t* q_ = bp + (int64_t)step_of(I) * N * 16;                                     \
-    const uint32_t d_ = bdst + ((I) % 3) * STAGE16_B;                                           \
+    const uint32_t d_ = bdst + (STAGE) * STAGE16_B;                                             \
     g6_glds16(q_, d_);                                                                          \
     g6_glds16(q_ + PL, d_ + PLANE16_B);                                                         \
     g6_glds16(q_ + 2 * PL, d_ + 2 * PLANE16_B);                                                 \
   }
-#define HOTK_G6_WRITE_A(SET, I)                                                                                   \
+#define HOTK_G6_WRITE_A(SET, STAGE)                                                                               \
   {                                                                                                               \
     g6_arrived(ra[SET][0]);                                                                                       \
     g6_arrived(ra[SET][1]);                                                                                       \
@@ -532,37 +543,69 @@ __global__ __launch_bounds__(G6_THREADS, 1) void k_gemm6_nn16(const float* __res
     g6_split_pair(g6_u2f(x_[2]), g6_u2f(x_[3]), h_[1], m_[1], l_[1]);                                             \
     g6_split_pair(g6_u2f(y_[0]), g6_u2f(y_[1]), h_[2], m_[2], l_[2]);                                             \
     g6_split_pair(g6_u2f(y_[2]), g6_u2f(y_[3]), h_[3], m_[3], l_[3]);                                             \
-    unsigned char* w_ = lds + P16_A0 + ((I) & 1) * STAGE16_A + aoff;                                              \
+    unsigned char* w_ = lds + P16_A0 + (STAGE) * STAGE16_A + aoff;                                                \
     *reinterpret_cast<u32x4*>(w_) = (u32x4){h_[0], h_[1], h_[2], h_[3]};                                          \
     *reinterpret_cast<u32x4*>(w_ + PLANE16_A) = (u32x4){m_[0], m_[1], m_[2], m_[3]};                              \
     *reinterpret_cast<u32x4*>(w_ + 2 * PLANE16_A) = (u32x4){l_[0], l_[1], l_[2], l_[3]};                          \
   }
+  // (wave-uniform) PP: the group that stages first -- it runs the same loop half a step behind: its staging of iteration i
+  // is that of step i + 1, and it names its two register sets the other way round, so that the loop body is one code
+  const int off = (PP && __builtin_amdgcn_readfirstlane(wm) != 0) ? 1 : 0;
   // prologue: steps 0 and 1 requested; step 0 staged
-  HOTK_G6_LOAD_A(0, 0)
-  HOTK_G6_DMA_B(0)
-  HOTK_G6_LOAD_A(1, 1)
-  HOTK_G6_DMA_B(1)
-  g6_wait_vm<5>();                                            // A(0), B(0) landed; A(1), B(1) may be in flight
-  HOTK_G6_WRITE_A(0, 0)
-  g6_barrier_lds();
-  // iteration i: request step i + 2, multiply step i, stage A of step i + 1 (its loads were requested an iteration ago)
+  if (off == 0) {
+    HOTK_G6_LOAD_A(0, 0)
+    HOTK_G6_DMA_B(0, 0)
+    HOTK_G6_LOAD_A(1, 1)
+    HOTK_G6_DMA_B(1, 1)
+    g6_wait_vm<5>();                                          // A(0), B(0) landed; A(1), B(1) may be in flight
+    HOTK_G6_WRITE_A(0, 0)
+    g6_barrier_lds();
+  } else {
+    HOTK_G6_LOAD_A(1, 0)
+    HOTK_G6_DMA_B(0, 0)
+    HOTK_G6_LOAD_A(0, 1)
+    HOTK_G6_DMA_B(1, 1)
+    g6_wait_vm<5>();
+    HOTK_G6_WRITE_A(1, 0)
+    g6_barrier_lds();
+    // its extra half step, while the first group multiplies step 0: request step 2, stage step 1
+    HOTK_G6_LOAD_A(1, 2)
+    HOTK_G6_DMA_B(2, 2)
+    g6_wait_vm<5>();
+    HOTK_G6_WRITE_A(0, 1)
+    g6_barrier_lds();
+  }
+  // iteration i: multiply step i; request step j + 2 and stage A of step j + 1, j = i + off (requested an iteration ago)
   for (int i0 = 0; i0 < S; i0 += 6) {
 #pragma unroll
     for (int u = 0; u < 6; ++u) {                             // 6 = lcm of the ring depths 2 and 3: static stage indices
       const int i = i0 + u;
-      HOTK_G6_LOAD_A(u & 1, i + 2)
-      HOTK_G6_DMA_B(i + 2)
-      if (HOTK_G6_PROBE_PROD(i < S, i == 0))
+      if (!PP) {
+        HOTK_G6_LOAD_A(u & 1, i + 2)
+        HOTK_G6_DMA_B(i + 2, (u + 2) % 3)
+      }
+      if (HOTK_G6_PROBE_PROD(i < S, i == 0)) {
+        if (PP) __builtin_amdgcn_s_setprio(1);
         g6_products16(lds + P16_A0 + (u & 1) * STAGE16_A, lds + P16_B0 + (u % 3) * STAGE16_B, wm, wn, lane, acc);
-      g6_wait_vm<5>();                                        // step i + 1 landed (A registers and B stage); step i + 2 in flight
-      HOTK_G6_WRITE_A((u + 1) & 1, i + 1)
+        if (PP) __builtin_amdgcn_s_setprio(0);
+      }
+      if (PP) {
+        g6_barrier_lds();
+        const int sb = (u + 2) % 3, sb1 = (u + 3) % 3;        // B stage of step j + 2
+        HOTK_G6_LOAD_A(u & 1, i + off + 2)
+        HOTK_G6_DMA_B(i + off + 2, off ? sb1 : sb)
+      }
+      g6_wait_vm<5>();                                        // step j + 1 landed (A registers and B stage); step j + 2 in flight
+      HOTK_G6_WRITE_A((u + 1) & 1, (u + 1 + off) & 1)
       g6_barrier_lds();
     }
   }
+  if (PP && off == 0) g6_barrier_lds();                        // the half step the other group spent in its prologue
 #undef HOTK_G6_LOAD_A
 #undef HOTK_G6_DMA_B
 #undef HOTK_G6_WRITE_A
   g6_drain();
+  g6_arrived(ra[0][0]); g6_arrived(ra[0][1]); g6_arrived(ra[1][0]); g6_arrived(ra[1][1]);   // (allocated until here: see g6_drain)
   g6_barrier_lds();                                           // the stages become the epilogue's staging image
   const bool full = (m0 + BM <= M) && (n0 + BN <= N) && (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 &&
                     (!bias || ((uintptr_t)bias & 15) == 0);
@@ -703,6 +746,8 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const floa
     }
   }
   g6_drain();
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) g6_wait_tn(ring[d]);
   float* P = partial + slab * (int64_t)K * N;
   const bool full = (N & 3) == 0 && ((uintptr_t)partial & 15) == 0;
   g6_store_tile(P, N, k0 + 32 * TM * wm, K - (k0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), nullptr, lds, wave,
@@ -791,10 +836,11 @@ namespace {
 // HOTK_G6_PIPE=1 selects the pipelined kernel (k step 16, planes [K/16][N][16]) for A/B runs; default: the two-phase one
 // (k step 32, planes [K/32][N][32]) -- they measure the same (0.93 / 0.90 ms on [254 k, 512] x [512, 512]), the simpler one
 // is kept.  One switch for hotk_gemm6_split_weight and hotk_gemm6_nn: the planes are theirs.
-bool g6_pipe() {
-  static const int v = [] { const char* e = getenv("HOTK_G6_PIPE"); return (e && e[0] == '1') ? 1 : 0; }();
-  return v != 0;
+int g6_pipe_mode() {
+  static const int v = [] { const char* e = getenv("HOTK_G6_PIPE"); return (e && e[0] >= '1' && e[0] <= '2') ? e[0] - '0' : 0; }();
+  return v;
 }
+bool g6_pipe() { return g6_pipe_mode() != 0; }
 
 // rows == nullptr: all M rows.  Otherwise the Mc listed rows (ascending, each < M); the other rows of C are zeroed.
 int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
@@ -819,11 +865,17 @@ int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, fl
   if (pipe) {
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (nwide + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
-    static int attr16 = hipFuncSetAttribute((const void*)k_gemm6_nn16, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)G6_LDS16) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
+    static int attr16 = (hipFuncSetAttribute((const void*)k_gemm6_nn16<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)G6_LDS16) == hipSuccess &&
+                         hipFuncSetAttribute((const void*)k_gemm6_nn16<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)G6_LDS16) == hipSuccess) ? HOTK_OK : HOTK_ELAUNCH;
     if (attr16) return attr16;
-    hipLaunchKernelGGL(k_gemm6_nn16, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS16, st, A, lda,
-                       (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
+    if (g6_pipe_mode() == 2)
+      hipLaunchKernelGGL(k_gemm6_nn16<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS16, st, A, lda,
+                         (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
+    else
+      hipLaunchKernelGGL(k_gemm6_nn16<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS16, st, A, lda,
+                         (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
     return hotk_launch_status();
   }
   return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, 0, nwide, rows, Mc, st);
