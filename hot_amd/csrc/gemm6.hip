@@ -226,6 +226,7 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
     }
     return;
   }
+  if (RM) return;      // (row lists: the entry point insists on the alignment of the staged path; nothing left to store here)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int n = 32 * j + cl;
@@ -236,11 +237,7 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t rr = 32 * i + rh + (r & 3) + 8 * (r >> 2);
-        if (rr < n_rows) {
-          const int64_t dst = RM ? (int64_t)rm.rows[row0 + rr] : row0 + rr;
-          C[dst * ldc + col0 + n] = acc[i][j][r] + b;
-          if (RM) g6_zero_gap<float>(C, ldc, col0 + n, row0 + rr, dst, g6_next_row(rm, row0 + rr));
-        }
+        if (rr < n_rows) C[(row0 + rr) * ldc + col0 + n] = acc[i][j][r] + b;
       }
   }
 }
@@ -849,6 +846,8 @@ int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, fl
   if (M == 0) return HOTK_OK;
   if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
   HOTK_CHECK_ARG(A && planes && C && hotk_aligned16(A) && hotk_aligned16(planes) && (lda & 3) == 0);
+  // (row lists: 16-byte pieces only -- the kernel's element-wise store path does not know the list)
+  if (rows && !((N & 3) == 0 && (ldc & 3) == 0 && hotk_aligned16(C) && (!bias || hotk_aligned16(bias)))) return HOTK_EUNSUPPORTED;
   if (rows && Mc == 0)
     return hipMemset2DAsync(C, (size_t)ldc * sizeof(float), 0, (size_t)N * sizeof(float), (size_t)M, st) == hipSuccess
                ? HOTK_OK : HOTK_ELAUNCH;

@@ -349,7 +349,7 @@ def mm(A, W, bias=None, trans_w=False, rows=None):
     planes = torch.empty(3, N, K, dtype=torch.bfloat16, device=A.device)
     call('hotk_gemm6_split_weight', 10 * K * N, p(w), ldw, K, N, 0 if trans_w else 1, p(planes))
     C = torch.empty(M, N, dtype=torch.float32, device=A.device)
-    if rows is None:
+    if rows is None or not _rows_ok(N, bias):
         call('hotk_gemm6_nn', 4 * M * (K + N), p(a), lda, p(planes), p(bias), p(C), N, M, K, N)
     else:
         call('hotk_gemm6_nn_rows', 4 * rows.numel() * (K + N), p(a), lda, p(planes), p(bias), p(C), N, M, K, N, p(rows),
@@ -357,9 +357,15 @@ def mm(A, W, bias=None, trans_w=False, rows=None):
     return C
 
 
-def mm_masks(A, W, rows, trans_w=False):
-    """whether mm(A, W, ., trans_w, rows) leaves the padding rows of its result zero by itself"""
-    return rows is not None and W.dtype == torch.float32 and mm6_ok(A, A.size(1), W.size(0) if trans_w else W.size(1))
+def _rows_ok(N, bias):
+    """hotk_gemm6_nn_rows stores 16-byte pieces only"""
+    return N % 4 == 0 and (bias is None or bias.data_ptr() % 16 == 0)
+
+
+def mm_masks(A, W, rows, trans_w=False, bias=None):
+    """whether mm(A, W, bias, trans_w, rows) leaves the padding rows of its result zero by itself"""
+    N = W.size(0) if trans_w else W.size(1)
+    return rows is not None and W.dtype == torch.float32 and mm6_ok(A, A.size(1), N) and _rows_ok(N, bias)
 
 
 def wgrad6_ok(A, B, rows=None):
@@ -780,7 +786,7 @@ class Proj22(Function):
         assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
         h2, xd, x2 = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
         vn, ve = valid_rows(plan, 'n'), valid_rows(plan, 'e')
-        if b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn)):
+        if b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn, False, b1)):
             h1 = mm(xd, W1, b1, rows=vn)   # the bias rides on the GEMM: no padding node rows, or the GEMM leaves them zero
         else:
             h1 = mm(xd, W1, rows=vn)
@@ -1241,7 +1247,7 @@ class AttnCore22(Function):
         else:
             ve = valid_rows(plan, 'e')
             y = mm(att, w_o, b_o, trans_w=True, rows=ve)
-            if padded and not mm_masks(att, w_o, ve, True):
+            if padded and not mm_masks(att, w_o, ve, True, b_o):
                 y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
             out = y.add_(skip).view(*h2.shape[:-1], D)
         ctx.save_for_backward(h1, h2, v, proj, w_o, att, kvg, phik, kvn)
