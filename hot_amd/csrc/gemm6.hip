@@ -854,13 +854,14 @@ int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, fl
   // a column tail of at most 128 goes to the 256 x 128 build of the kernel (N = 320: one 256-wide and one 128-wide tile
   // instead of two 256-wide ones, the second three quarters empty)
   const int64_t tail = N % BN;
-  const bool pipe = g6_pipe() && !rows;
+  const bool pipe = g6_pipe() && !rows && BN == 256;
   const bool split_tail = !pipe && tail > 0 && tail <= 128;
   const int64_t nwide = split_tail ? N - tail : N;
   if (split_tail) {
     const int rc = hotk_gemm6_nn_cols_n128(A, lda, planes, bias, C, ldc, M, K, N, nwide, N, rows, Mc, st);
     if (rc || nwide == 0) return rc;
   }
+#if HOTK_G6_BN == 256
   if (pipe) {
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (nwide + BN - 1) / BN;
     if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
@@ -877,6 +878,7 @@ int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, fl
                          (const uint16_t*)planes, bias, C, ldc, M, (int)K, (int)N, (int)tiles_n);
     return hotk_launch_status();
   }
+#endif
   return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, 0, nwide, rows, Mc, st);
 }
 
