@@ -100,6 +100,7 @@ _SIGNATURES.update({
     'hotk_gemm6_tn': [_P, _L, _P, _L, _P, _L, _L, _L, _P],
     'hotk_gemm6_nn_rows': [_P, _L, _P, _P, _P, _L, _L, _L, _L, _P, _L, _P],
     'hotk_gemm6_tn_rows': [_P, _L, _P, _L, _P, _L, _L, _L, _P, _L, _P],
+    'hotk_gemm6_entry22': [_P, _L, _P, _P, _L, _L, _L, _L, _P, _L, _P, _L, _P, _P, _P],
     'hotk_linear22_entry_fwd_bf16': [_P, _L, _P, _L, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_assemble22_bf16': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_seg_sum_rows_bf16': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],

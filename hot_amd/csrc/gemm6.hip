@@ -170,7 +170,13 @@ constexpr int G6_ST = 32 * TN + 4;   // floats per staged row
 // Row map (RM): the tile's rows are entries row0 .. of the ascending list `rows` [Mc] of the rows of C [Mall, .] that carry
 // data (the others are padding).  The lane that stores listed row i also writes zeros to the padding rows between it and
 // the next listed row (the first one: and before it; the last one: up to Mall), so that C leaves fully written.
-struct RowMap { const int32_t* rows; int64_t Mc, Mall; };
+// Row MODE of the NN kernel: 0 = all rows, 1 = row list, 2 = row RECORDS with the assembly of Linear(2, 2, 'light') as the
+// epilogue (hotk_gemm6_entry22): rec[i] = {row, next listed row (or Mall), row node, column node or -1 on the diagonal},
+// y = z + yn[row node][C..2C) + yn[column node][2C..3C) + b_off off the diagonal, yn[node][0..C) + b_diag on it.
+struct RowMap {
+  const int32_t* rows; int64_t Mc, Mall;
+  const int4* rec; const float* yn; int64_t ld_yn; const float* b_off; const float* b_diag; int C;
+};
 __device__ __forceinline__ int64_t g6_next_row(const RowMap& rm, int64_t i) { return i + 1 < rm.Mc ? rm.rows[i + 1] : rm.Mall; }
 // (nxt = g6_next_row(rm, i), fetched by the caller together with its other list reads: one round trip, not one per row)
 template <class V>
@@ -181,10 +187,11 @@ __device__ __forceinline__ void g6_zero_gap(float* __restrict__ C, int64_t ldc, 
   if (i == 0)
     for (int64_t g = 0; g < r; ++g) *reinterpret_cast<V*>(C + g * ldc + col) = z;
 }
-template <bool RM = false>
+template <int MODE = 0>
 __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc, int64_t row0, int64_t n_rows, int col0,
                                               int n_cols, const float* __restrict__ bias, unsigned char* lds, int wave, int lane,
-                                              const f32x16 (&acc)[TM][TN], bool full, const RowMap rm = RowMap{nullptr, 0, 0}) {
+                                              const f32x16 (&acc)[TM][TN], bool full, const RowMap rm = RowMap{}) {
+  constexpr bool RM = MODE != 0;
   const int cl = lane & 31, rh = 4 * (lane >> 5);
   // `full` here: 16-byte pieces are possible (alignment of C, ldc, bias: the caller's check).  Rows past n_rows and
   // 4-column pieces past n_cols are skipped lane by lane, so edge tiles take this path too when n_cols % 4 == 0.
@@ -193,18 +200,41 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
     float* st = reinterpret_cast<float*>(lds) + wave * (32 * G6_ST);
     const int row = lane >> 4, c4 = lane & 15;
     const bool col_in = 4 * c4 < n_cols;
-    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias && col_in) b4 = *reinterpret_cast<const float4*>(bias + col0 + 4 * c4);
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), bd4 = b4;
+    const int cc = col0 + 4 * c4;                     // this lane's four columns
+    if (MODE == 2) {
+      if (rm.b_off && col_in) b4 = *reinterpret_cast<const float4*>(rm.b_off + cc);
+      if (rm.b_diag && col_in) bd4 = *reinterpret_cast<const float4*>(rm.b_diag + cc);
+    } else if (bias && col_in) {
+      b4 = *reinterpret_cast<const float4*>(bias + cc);
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
       int64_t dst[8], nxt[8];
+      float4 ga[8], gb[8];                            // MODE 2: the two gathered node rows of each stored row
+      bool diag[8];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const int64_t ti = 32 * i + 4 * q + row;      // row of the wave's tile
         dst[q] = row0 + (ti < n_rows ? ti : n_rows - 1);
-        if (RM) {
+        if (MODE == 1) {
           nxt[q] = g6_next_row(rm, dst[q]);
           dst[q] = rm.rows[dst[q]];
+        }
+      }
+      if (MODE == 2) {
+        int4 rc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) rc[q] = rm.rec[dst[q]];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          dst[q] = rc[q].x;
+          nxt[q] = rc[q].y;
+          diag[q] = rc[q].w < 0;
+          const float* pa = rm.yn + (int64_t)rc[q].z * rm.ld_yn + (diag[q] ? 0 : rm.C) + cc;
+          const float* pb = rm.yn + (int64_t)(diag[q] ? rc[q].z : rc[q].w) * rm.ld_yn + 2 * rm.C + cc;
+          ga[q] = col_in ? *reinterpret_cast<const float4*>(pa) : make_float4(0.f, 0.f, 0.f, 0.f);
+          gb[q] = (col_in && !diag[q]) ? *reinterpret_cast<const float4*>(pb) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -219,9 +249,19 @@ __device__ __forceinline__ void g6_store_tile(float* __restrict__ C, int64_t ldc
       for (int q = 0; q < 8; ++q) {
         if (!col_in || 32 * i + 4 * q + row >= n_rows) continue;
         float4 v = *reinterpret_cast<const float4*>(st + (4 * q + row) * G6_ST + 4 * c4);
-        v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
-        *reinterpret_cast<float4*>(C + dst[q] * ldc + col0 + 4 * c4) = v;
-        if (RM) g6_zero_gap<float4>(C, ldc, col0 + 4 * c4, row0 + 32 * i + 4 * q + row, dst[q], nxt[q]);
+        if (MODE == 2) {
+          // (the order of hotk_assemble22's additions: the two forms agree bit for bit)
+          if (diag[q]) {
+            v = make_float4(ga[q].x + bd4.x, ga[q].y + bd4.y, ga[q].z + bd4.z, ga[q].w + bd4.w);
+          } else {
+            v.x = ((v.x + ga[q].x) + gb[q].x) + b4.x; v.y = ((v.y + ga[q].y) + gb[q].y) + b4.y;
+            v.z = ((v.z + ga[q].z) + gb[q].z) + b4.z; v.w = ((v.w + ga[q].w) + gb[q].w) + b4.w;
+          }
+        } else {
+          v.x += b4.x; v.y += b4.y; v.z += b4.z; v.w += b4.w;
+        }
+        *reinterpret_cast<float4*>(C + dst[q] * ldc + cc) = v;
+        if (RM) g6_zero_gap<float4>(C, ldc, cc, row0 + 32 * i + 4 * q + row, dst[q], nxt[q]);
       }
     }
     return;
@@ -342,7 +382,7 @@ __device__ __forceinline__ void g6_store_nn(unsigned char* lds_a, unsigned char*
   }
 }
 
-template <bool RM>
+template <int MODE>
 __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const float* __restrict__ A, int64_t lda,
                                                                       const uint16_t* __restrict__ planes,
                                                                       const float* __restrict__ bias, float* __restrict__ C,
@@ -369,7 +409,8 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
     const int pi = t + q * G6_THREADS;
     int64_t arow = m0 + g6_piece_row(pi);
     if (arow >= M) arow = M - 1;
-    if (RM) arow = rm.rows[arow];
+    if (MODE == 1) arow = rm.rows[arow];
+    if (MODE == 2) arow = rm.rec[arow].x;
     ap[q] = A + arow * lda + 8 * g6_piece_quarter(pi);
   }
 #pragma unroll
@@ -408,7 +449,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_nn(const floa
 #pragma unroll
   for (int d = 0; d < DEPTH; ++d) g6_wait_nn(ring[d]);      // the ring's registers stay allocated until the drain (see g6_drain)
   const bool full = (ldc & 3) == 0 && ((uintptr_t)C & 15) == 0 && (!bias || ((uintptr_t)bias & 15) == 0);
-  g6_store_tile<RM>(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), bias, lds,
+  g6_store_tile<MODE>(C, ldc, m0 + 32 * TM * wm, M - (m0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), bias, lds,
                     wave, lane, acc, full, rm);
 }
 
@@ -780,26 +821,23 @@ int g6_attr(F f) {
                                                                                                                     : HOTK_ELAUNCH;
 }
 
-// columns [col0, ncap) of C = A . B on this build's tiles; rows: see hotk_gemm6_nn_rows
-int g6_launch_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
-                 int64_t N, int64_t col0, int64_t ncap, const int32_t* rows, int64_t Mc, hipStream_t st) {
-  const int64_t Mt = rows ? Mc : M;
+// columns [col0, ncap) of C = A . B on this build's tiles; rm.rows / rm.rec: see hotk_gemm6_nn_rows / hotk_gemm6_entry22
+template <int MODE>
+int g6_launch_mode(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t Mt, int64_t K,
+                   int64_t N, int64_t col0, int64_t ncap, const RowMap& rm, hipStream_t st) {
   const int64_t tiles_m = (Mt + BM - 1) / BM, tiles_n = (ncap - col0 + BN - 1) / BN;
   if (tiles_m * tiles_n > 0x7fffffffll) return HOTK_EUNSUPPORTED;
-  const dim3 grid((unsigned)(tiles_m * tiles_n));
-  const RowMap rm{rows, Mc, M};
-  if (rows) {
-    static int attr = g6_attr(k_gemm6_nn<true>);
-    if (attr) return attr;
-    hipLaunchKernelGGL(k_gemm6_nn<true>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, (const uint16_t*)planes, bias, C, ldc, Mt,
-                       (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap, rm);
-  } else {
-    static int attr = g6_attr(k_gemm6_nn<false>);
-    if (attr) return attr;
-    hipLaunchKernelGGL(k_gemm6_nn<false>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, (const uint16_t*)planes, bias, C, ldc, Mt,
-                       (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap, rm);
-  }
+  static int attr = g6_attr(k_gemm6_nn<MODE>);
+  if (attr) return attr;
+  hipLaunchKernelGGL(k_gemm6_nn<MODE>, dim3((unsigned)(tiles_m * tiles_n)), dim3(G6_THREADS), G6_LDS, st, A, lda,
+                     (const uint16_t*)planes, bias, C, ldc, Mt, (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap, rm);
   return hotk_launch_status();
+}
+int g6_launch_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
+                 int64_t N, int64_t col0, int64_t ncap, const RowMap& rm, hipStream_t st) {
+  if (rm.rec) return g6_launch_mode<2>(A, lda, planes, bias, C, ldc, rm.Mc, K, N, col0, ncap, rm, st);
+  if (rm.rows) return g6_launch_mode<1>(A, lda, planes, bias, C, ldc, rm.Mc, K, N, col0, ncap, rm, st);
+  return g6_launch_mode<0>(A, lda, planes, bias, C, ldc, M, K, N, col0, ncap, rm, st);
 }
 
 }  // namespace HOTK_G6_NS
@@ -813,14 +851,14 @@ using namespace HOTK_G6_NS;
 #define HOTK_G6_CAT(a, b) HOTK_G6_CAT2(a, b)
 extern "C" int HOTK_G6_CAT(hotk_gemm6_nn_cols, HOTK_G6_VARIANT)(const float* A, int64_t lda, const void* planes, const float* bias,
                                                                  float* C, int64_t ldc, int64_t M, int64_t K, int64_t N,
-                                                                 int64_t col0, int64_t ncap, const int32_t* rows, int64_t Mc,
-                                                                 void* stream) {
-  return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, col0, ncap, rows, Mc, (hipStream_t)stream);
+                                                                 int64_t col0, int64_t ncap, const void* row_map, void* stream) {
+  return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, col0, ncap, *static_cast<const RowMap*>(row_map), (hipStream_t)stream);
 }
 #else
+// (row_map: the RowMap of this file, same layout in both builds)
 extern "C" int hotk_gemm6_nn_cols_n128(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
-                                       int64_t M, int64_t K, int64_t N, int64_t col0, int64_t ncap, const int32_t* rows,
-                                       int64_t Mc, void* stream);
+                                       int64_t M, int64_t K, int64_t N, int64_t col0, int64_t ncap, const void* row_map,
+                                       void* stream);
 extern "C" int hotk_gemm6_nn_supported(int64_t M, int64_t K, int64_t N) {
   return (M > 0 && K >= 32 && K % 32 == 0 && N >= 1 && K <= (1 << 20) && N <= (1 << 20) && M < ((int64_t)1 << 40)) ? 1 : 0;
 }
@@ -841,7 +879,9 @@ bool g6_pipe() { return g6_pipe_mode() != 0; }
 
 // rows == nullptr: all M rows.  Otherwise the Mc listed rows (ascending, each < M); the other rows of C are zeroed.
 int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
-          int64_t N, const int32_t* rows, int64_t Mc, hipStream_t st) {
+          int64_t N, const RowMap& rm, hipStream_t st) {
+  const bool rows = rm.rows || rm.rec;      // a list of rows (plain, or as records)
+  const int64_t Mc = rm.Mc;
   HOTK_CHECK_ARG(M >= 0 && lda >= K && ldc >= N && (!rows || (Mc >= 0 && Mc <= M && M <= 0x7fffffffll)));
   if (M == 0) return HOTK_OK;
   if (!hotk_gemm6_nn_supported(M, K, N)) return HOTK_EUNSUPPORTED;
@@ -858,7 +898,7 @@ int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, fl
   const bool split_tail = !pipe && tail > 0 && tail <= 128;
   const int64_t nwide = split_tail ? N - tail : N;
   if (split_tail) {
-    const int rc = hotk_gemm6_nn_cols_n128(A, lda, planes, bias, C, ldc, M, K, N, nwide, N, rows, Mc, st);
+    const int rc = hotk_gemm6_nn_cols_n128(A, lda, planes, bias, C, ldc, M, K, N, nwide, N, &rm, st);
     if (rc || nwide == 0) return rc;
   }
 #if HOTK_G6_BN == 256
@@ -879,7 +919,7 @@ int g6_nn(const float* A, int64_t lda, const void* planes, const float* bias, fl
     return hotk_launch_status();
   }
 #endif
-  return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, 0, nwide, rows, Mc, st);
+  return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, 0, nwide, rm, st);
 }
 
 int g6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K, int64_t N,
@@ -918,14 +958,27 @@ extern "C" int hotk_gemm6_split_weight(const float* W, int64_t ldw, int64_t K, i
 
 extern "C" int hotk_gemm6_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
                              int64_t M, int64_t K, int64_t N, void* stream) {
-  return g6_nn(A, lda, planes, bias, C, ldc, M, K, N, nullptr, 0, (hipStream_t)stream);
+  return g6_nn(A, lda, planes, bias, C, ldc, M, K, N, RowMap{}, (hipStream_t)stream);
 }
 
 extern "C" int hotk_gemm6_nn_rows(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
                                   int64_t M, int64_t K, int64_t N, const int32_t* rows, int64_t n_rows, void* stream) {
   HOTK_CHECK_ARG(rows || n_rows == 0);
   if (!rows) return hotk_gemm6_nn(A, lda, planes, bias, C, ldc, M, K, N, stream);
-  return g6_nn(A, lda, planes, bias, C, ldc, M, K, N, rows, n_rows, (hipStream_t)stream);
+  RowMap rm{};
+  rm.rows = rows; rm.Mc = n_rows; rm.Mall = M;
+  return g6_nn(A, lda, planes, bias, C, ldc, M, K, N, rm, (hipStream_t)stream);
+}
+
+extern "C" int hotk_gemm6_entry22(const float* A, int64_t lda, const void* planes, float* Y, int64_t ldy, int64_t M, int64_t K,
+                                  int64_t N, const int32_t* rec, int64_t n_rows, const float* yn, int64_t ld_yn,
+                                  const float* b_off, const float* b_diag, void* stream) {
+  HOTK_CHECK_ARG(rec && yn && n_rows > 0 && ld_yn >= 3 * N && (ld_yn & 3) == 0 && hotk_aligned16(rec) && hotk_aligned16(yn) &&
+                 (!b_off || hotk_aligned16(b_off)) && (!b_diag || hotk_aligned16(b_diag)));
+  RowMap rm{};
+  rm.rec = reinterpret_cast<const int4*>(rec); rm.Mc = n_rows; rm.Mall = M;
+  rm.yn = yn; rm.ld_yn = ld_yn; rm.b_off = b_off; rm.b_diag = b_diag; rm.C = (int)N;
+  return g6_nn(A, lda, planes, nullptr, Y, ldy, M, K, N, rm, (hipStream_t)stream);
 }
 
 extern "C" int hotk_gemm6_tn_partials(int64_t M, int64_t K, int64_t N, int64_t* n_partials) {

@@ -328,6 +328,29 @@ def valid_rows(plan, level):
     return d[key]
 
 
+def entry_records(plan):
+    """int32 [n, 4] per valid entry row, ascending: {row, next valid row (R after the last), row node, column node or -1 on
+    the diagonal} -- what hotk_gemm6_entry22's epilogue reads per stored row.  Built once per plan."""
+    d = plan.__dict__
+    if '_entry_rec' not in d:
+        rows = valid_rows(plan, 'e')
+        if rows is None:
+            rows = torch.arange(plan.R, dtype=torch.int32, device=plan.kind.device)
+        r = rows.long()
+        nxt = torch.cat([rows[1:], torch.tensor([plan.R], dtype=torch.int32, device=rows.device)])
+        cn = torch.where(plan.kind[r] == 1, torch.full_like(rows, -1), plan.coln[r])
+        d['_entry_rec'] = torch.stack([rows, nxt, plan.rown[r], cn], dim=1).contiguous()
+    return d['_entry_rec']
+
+
+def entry22_ok(x2, K, N, b_off, b_diag, plan):
+    return (_G6_ROWS and _G6_ENTRY and mm6_ok(x2, K, N) and N % 4 == 0 and plan.R < (1 << 31) and plan.Ev > 0
+            and all(b is None or b.data_ptr() % 16 == 0 for b in (b_off, b_diag)))
+
+
+_G6_ENTRY = os.environ.get('HOTK_GEMM6_ENTRY', '1') == '1'
+
+
 def mm(A, W, bias=None, trans_w=False, rows=None):
     """A[M, K] @ W[K, N] (+ bias), or A[M, K] @ W[N, K]^T with trans_w: the split-bf16 tiled GEMM for tall, wide products
     (fp32-exact: six bf16 MFMAs per product on three-way exact splits, weight split once per call), the library otherwise.
@@ -689,6 +712,15 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
         y = torch.empty(n, C, dtype=xs.dtype, device=dev)
         call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
              p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
+    elif entry22_ok(x2, 2 * D, C, b_off, b_diag, plan):
+        # the same on the tiled GEMM (wide layers): products over the valid rows, assembly in the epilogue, padding rows zero
+        w2, ldw = _row_major(W[D:3 * D])
+        planes = torch.empty(3, C, 2 * D, dtype=torch.bfloat16, device=dev)
+        call('hotk_gemm6_split_weight', 10 * 2 * D * C, p(w2), ldw, 2 * D, C, 1, p(planes))
+        rec = entry_records(plan)
+        y = torch.empty(n, C, dtype=xs.dtype, device=dev)
+        call('hotk_gemm6_entry22', 4 * rec.size(0) * (2 * D + C), p(x2), 2 * D, p(planes), p(y), C, n, 2 * D, C, p(rec),
+             rec.size(0), p(yn), 3 * C, p(b_off), p(b_diag))
     else:
         y = mm(x2, W[D:3 * D], rows=valid_rows(plan, 'e'))
         call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),

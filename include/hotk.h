@@ -310,6 +310,16 @@ int hotk_gemm6_nn_rows(const float* A, int64_t lda, const void* planes, const fl
                        int64_t K, int64_t N, const int32_t* rows, int64_t n_rows, void* stream);
 int hotk_gemm6_tn_rows(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t M, int64_t K, int64_t N,
                        const int32_t* rows, int64_t n_rows, void* stream);
+/* The entry GEMM of the factored Linear(2, 2, 'light') with its assembly as the epilogue, over row RECORDS (the tiled-GEMM
+ * form of hotk_linear22_entry_fwd, for widths the LDS-resident thin GEMM does not take): rec[i] = {row, next listed row
+ * (M after the last), row node, column node or -1 on the diagonal}, i < n_rows, rows ascending;
+ *   off-diagonal row: Y = A . B + yn[row node][N..2N) + yn[column node][2N..3N) + b_off
+ *   diagonal row    : Y = yn[node][0..N) + b_diag                   every row that is not listed: zeros
+ * replaces get_output's matmul + _Bias._2 + apply_mask(0) (models/sparse/linear.py:46-48,297-306,345-346) and
+ * hotk_assemble22's pass over Y.  N % 4 == 0, Y / yn / biases 16-byte aligned. */
+int hotk_gemm6_entry22(const float* A, int64_t lda, const void* planes, float* Y, int64_t ldy, int64_t M, int64_t K, int64_t N,
+                       const int32_t* rec, int64_t n_rows, const float* yn, int64_t ld_yn, const float* b_off,
+                       const float* b_diag, void* stream);
 
 /* LayerNorm over the rows of a batch with the padding mask folded in: y[r] = (keep >> kind[r]) & 1 ? LN(x[r]) * gamma +
  * beta : 0 (kind NULL: every row), stats[r] = {mean, rstd} for the backward.  replaces Apply(nn.LayerNorm) + batch_like's

@@ -20,7 +20,7 @@ def test_no_instruction_touches_a_register_with_a_load_in_flight(src, tmp_path):
     out = build.assembly(os.path.join(CSRC, src), str(tmp_path / (src + '.s')))
     found = scan_file(out, 'k_gemm6')
     default = {k: v for k, v in found.items() if 'k_gemm6_nn16' not in k}      # (nn16: opt-in A/B kernels, HOTK_G6_PIPE)
-    assert any('k_gemm6_nnILb1' in k for k in default) and any('k_gemm6_nnILb0' in k for k in default)
+    assert all(any('k_gemm6_nnILi%dE' % mode in k for k in default) for mode in (0, 1, 2))      # all rows / row list / records
     if src == 'gemm6.hip':
         assert any('k_gemm6_tnILb1' in k for k in default) and any('k_gemm6_tnILb0' in k for k in default)
     for name, report in default.items():

@@ -1055,3 +1055,62 @@ def test_gemm6_over_listed_rows(M, K, N, keep):
         assert not torch.isnan(dW).any()
         assert rel_err(dW.cpu(), refw.cpu()) < 2e-6 if rows.numel() else float(dW.abs().max()) == 0.0
         assert torch.equal(dW, ops.wgrad6(A, G, rows))
+
+
+@pytest.mark.parametrize('D,C,with_bias', [(256, 512, True), (256, 256, False), (160, 320, True)])
+def test_linear22_light_wide_entry_gemm_epilogue(D, C, with_bias):
+    """hotk_gemm6_entry22: the factored Linear(2, 2, 'light') at widths the thin GEMM does not take, entry GEMM over the valid
+    rows with the assembly (gathered node rows, both biases, zeros on padding) in its epilogue -- bit for bit the tiled GEMM
+    over the row list followed by hotk_assemble22, and against the dense five-block formula in float64.  Ragged batch: graphs
+    of 3..14 nodes (padding rows inside every graph), one graph without edges."""
+    _lib, ops, make_batch, *_ = _product()
+    from hot_amd.batch.sparse import make_batch_concatenated
+    rng = np.random.default_rng(D + C)
+    nn_, ne_, eis = [], [], []
+    for b in range(700):
+        n = int(rng.integers(3, 15))
+        und = set()
+        for _ in range(0 if b == 5 else int(1.3 * n)):
+            i, j = rng.integers(0, n, 2)
+            if i != j:
+                und.add((min(i, j), max(i, j)))
+        e = sorted([(i, j) for i, j in und] + [(j, i) for i, j in und])
+        eis.append(np.array(e, dtype=np.int64).reshape(-1, 2).T); nn_.append(n); ne_.append(len(e))
+    ei = torch.from_numpy(np.concatenate(eis, axis=1)).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    # (node and edge features side by side: D channels in all)
+    G = make_batch_concatenated(torch.randn(sum(nn_), D // 2, generator=g).to(DEV), ei,
+                                torch.randn(sum(ne_), D // 2, generator=g).to(DEV), nn_, ne_)
+    plan = G.plan
+    assert plan.R >= ops.G6_MIN_ROWS and plan.Ev < plan.R
+    W = (torch.randn(5 * D, C, generator=g) / D ** 0.5).to(DEV)
+    b_off = torch.randn(C, generator=g).to(DEV) if with_bias else None
+    b_diag = torch.randn(C, generator=g).to(DEV) if with_bias else None
+    x = G.values.reshape(plan.R, D)
+    _lib.timing_begin(None)
+    y1, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+    ran = _lib.timing_end()
+    assert 'hotk_gemm6_entry22' in ran and 'hotk_assemble22' not in ran
+    ops._G6_ENTRY = False
+    try:
+        _lib.timing_begin(None)
+        y2, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+        assert 'hotk_assemble22' in _lib.timing_end()
+    finally:
+        ops._G6_ENTRY = True
+    assert torch.equal(y1, y2)
+    valid = plan.kind != 0
+    assert float(y1[~valid].abs().max()) == 0.0
+    # the five-block formula in float64 on the valid rows
+    xd64 = x.double()
+    r = torch.nonzero(valid).view(-1)
+    rn, cn, tp = plan.rown[r].long(), plan.coln[r].long(), plan.tpos[r].long()
+    dpos = plan.diag_pos.long()
+    off = plan.kind[r] == 2
+    W64 = W.double()
+    ref = torch.zeros(r.numel(), C, dtype=torch.float64, device=DEV)
+    xt = torch.where((tp >= 0)[:, None], xd64[tp.clamp(min=0)], torch.zeros_like(xd64[r]))
+    ref[off] = (xd64[r] @ W64[D:2 * D] + xt @ W64[2 * D:3 * D] + xd64[dpos[rn]] @ W64[3 * D:4 * D]
+                + xd64[dpos[cn]] @ W64[4 * D:5 * D])[off] + (b_off.double() if with_bias else 0.)
+    ref[~off] = (xd64[r] @ W64[0:D])[~off] + (b_diag.double() if with_bias else 0.)
+    assert rel_err(y1[r].cpu(), ref.cpu()) < 3e-6
