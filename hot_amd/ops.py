@@ -349,6 +349,7 @@ def entry22_ok(x2, K, N, b_off, b_diag, plan):
 
 
 _G6_ENTRY = os.environ.get('HOTK_GEMM6_ENTRY', '1') == '1'
+_L22_SKIP_MASK = os.environ.get('HOTK_L22_SKIP_MASK', '1') == '1'      # (A/B switch: see _l22_backward)
 
 
 def mm(A, W, bias=None, trans_w=False, rows=None):
@@ -735,8 +736,15 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     D, C = xd.size(1), W.size(1)
     dev = g.device
     vn, ve = valid_rows(plan, 'n'), valid_rows(plan, 'e')
-    if plan.Ev != plan.R:
-        g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)      # padding rows of an upstream gradient may hold anything
+    # Padding rows of an upstream gradient may hold anything.  They are zeroed first -- unless nothing below reads them:
+    # the gather and the segment sums go through the plan's indices (valid rows only), and the two products skip them
+    # when both run on the tiled GEMMs over the row list (then the pass over [R, C] is saved: 25 of them per C2 step).
+    uses_thin = g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)      # (the thin GEMM reads every row)
+    skips_padding = (_L22_SKIP_MASK and ve is not None
+                     and (not want_dx or (not uses_thin and mm_masks(g, W[D:3 * D], ve, True)))
+                     and (not want_dw or wgrad6_ok(x2, g, ve)))
+    if plan.Ev != plan.R and not skips_padding:
+        g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
     # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
     dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
     call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)

@@ -1114,3 +1114,26 @@ def test_linear22_light_wide_entry_gemm_epilogue(D, C, with_bias):
                 + xd64[dpos[cn]] @ W64[4 * D:5 * D])[off] + (b_off.double() if with_bias else 0.)
     ref[~off] = (xd64[r] @ W64[0:D])[~off] + (b_diag.double() if with_bias else 0.)
     assert rel_err(y1[r].cpu(), ref.cpu()) < 3e-6
+    # backward: nothing reads the padding rows of the incoming gradient when both products run over the row list, so the
+    # mask pass over it is skipped -- NaN there must not reach any result, and every gradient is bit for bit the masked run's
+    gy = torch.randn(plan.R, C, generator=g).to(DEV)
+    gy[~valid] = float('nan')
+
+    def grads(skip):
+        ops._L22_SKIP_MASK = skip
+        try:
+            xr = x.detach().clone().requires_grad_(True)
+            Wr = W.detach().clone().requires_grad_(True)
+            bs = [b.detach().clone().requires_grad_(True) for b in (b_off, b_diag)] if with_bias else [None, None]
+            _lib.timing_begin(None)
+            ops.Linear22Light.apply(xr, Wr, bs[0], bs[1], plan).backward(gy)
+            ran = _lib.timing_end()
+            return ran, [xr.grad, Wr.grad] + [b.grad for b in bs if b is not None]
+        finally:
+            ops._L22_SKIP_MASK = True
+    ran_on, g_on = grads(True)
+    ran_off, g_off = grads(False)
+    # ([., 320]^T [., 320] is not taken by the tiled weight gradient (1.6 x padded tiles): the library reads every row, the mask stays)
+    assert ('hotk_mask_rows' not in ran_on) == ((D, C) != (160, 320)) and 'hotk_mask_rows' in ran_off
+    for a, b in zip(g_on, g_off):
+        assert torch.isfinite(a).all() and torch.equal(a, b)
