@@ -49,7 +49,7 @@ class SelfAttn(nn.Module):
         nn.init.constant_(self.fc_o.bias, 0.)
 
     def _values(self, G: B):
-        v = batch_like(G, self.fc_v(G.values), skip_masking=False)
+        v = batch_like(G, ops.linear_rows(G.values, self.fc_v), skip_masking=False)
         return [batch_like(G, x, skip_masking=True) for x in v.values.split(self.dim_v, -1)]
 
     def _1_to_0(self, G: B):

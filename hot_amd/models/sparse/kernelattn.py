@@ -83,7 +83,7 @@ class KernelSelfAttn(nn.Module):
         return [batch_like(H, v, skip_masking=True) for v in phi.values.split([g * F for g in groups], -1)]
 
     def _values(self, G: B):
-        v = batch_like(G, self.fc_v(G.values), skip_masking=False)
+        v = batch_like(G, ops.linear_rows(G.values, self.fc_v), skip_masking=False)
         return [batch_like(G, x, skip_masking=True) for x in v.values.split(self.dim_v, -1)]
 
     def _project_out(self, H: B, att_list):
@@ -94,7 +94,7 @@ class KernelSelfAttn(nn.Module):
             raise RuntimeError(f"mat1 and mat2 shapes cannot be multiplied: {len(att_list)} attention terms "
                                f"for an fc_o built for {n_v} (cfg='local' is unusable in the reference as well)")
         x = torch.cat(self.mu_dropout([a.values for a in att_list]), -1)
-        return batch_like(H, self.fc_o(self.dropout(x)), skip_masking=False)
+        return batch_like(H, ops.linear_rows(self.dropout(x), self.fc_o), skip_masking=False)
 
     # -- order-specific forwards ------------------------------------------------------------------------
     def _1_to_1(self, G: B):
@@ -103,7 +103,7 @@ class KernelSelfAttn(nn.Module):
         q_1 = self._phi_slots(h_1, 0, 1, True)[0]
         k_1 = self._phi_slots(h_1, 1, 2, False)[0]
         att_1 = self.att_1_1(q_1, k_1, self._values(G)[0])
-        att = batch_like(G, self.fc_o(self.dropout(att_1.values)), skip_masking=False)
+        att = batch_like(G, ops.linear_rows(self.dropout(att_1.values), self.fc_o), skip_masking=False)
         return add_batch(non_att, att)
 
     def _2_to_1(self, G: B):
