@@ -5,6 +5,7 @@ hot_amd/libhotk.so.  Objects live under hot_amd/csrc/_obj/ (git-ignored)."""
 import glob
 import hashlib
 import os
+import re
 import subprocess
 import sys
 from concurrent.futures import ThreadPoolExecutor
@@ -24,6 +25,16 @@ def _headers():
     return glob.glob(os.path.join(HERE, 'csrc', '*.h')) + [os.path.join(HERE, '..', 'include', 'hotk.h')]
 
 
+def _src_time(src):
+    """mtime of a source and of the csrc files it includes by name (gemm6_n128.hip is a second build of gemm6.hip)"""
+    t = os.path.getmtime(src)
+    for m in re.finditer(r'^#include "([^"]+\.hip)"', open(src).read(), re.M):
+        inc = os.path.join(os.path.dirname(src), m.group(1))
+        if os.path.exists(inc):
+            t = max(t, os.path.getmtime(inc))
+    return t
+
+
 def build(force=False, verbose=True, extra_flags=(), out=OUT):
     """extra_flags / out: A/B builds of the same ABI (load with HOTK_LIB=<out>)"""
     srcs = sources()
@@ -40,7 +51,7 @@ def build(force=False, verbose=True, extra_flags=(), out=OUT):
     jobs = []
     for s in srcs:
         o = os.path.join(OBJ, os.path.basename(s)[:-4] + tag + '.o')
-        if force or not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(s), hdr_time):
+        if force or not os.path.exists(o) or os.path.getmtime(o) < max(_src_time(s), hdr_time):
             jobs.append([hipcc] + FLAGS + list(extra_flags) + ['-c', s, '-o', o])
     objs = [os.path.join(OBJ, os.path.basename(s)[:-4] + tag + '.o') for s in srcs]
     if not jobs and os.path.exists(out) and all(os.path.getmtime(out) >= os.path.getmtime(o) for o in objs):

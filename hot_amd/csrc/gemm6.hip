@@ -724,7 +724,8 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const floa
                                                                       const float* __restrict__ G, int64_t ldg,
                                                                       float* __restrict__ partial, int64_t M, int K, int N,
                                                                       int tiles_k, int tiles_n, int64_t rows_per_slab,
-                                                                      const int32_t* __restrict__ rows) {
+                                                                      const int32_t* __restrict__ rows, int col0, int ncap) {
+  // columns [col0, ncap) of the product (N = all columns of G: the row stride of the partial blocks)
   extern __shared__ __align__(16) unsigned char lds[];
   unsigned char* lds_a = lds;
   unsigned char* lds_b = lds + OPER_A;
@@ -733,7 +734,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const floa
   const int64_t slab = bid / (tiles_k * tiles_n);
   const int rem = (int)(bid - slab * (tiles_k * tiles_n));
   const int tk = rem / tiles_n, tn = rem - tk * tiles_n;
-  const int k0 = tk * BM, n0 = tn * BN;
+  const int k0 = tk * BM, n0 = col0 + tn * BN;
   const int64_t r0 = slab * rows_per_slab;
   int64_t r1 = r0 + rows_per_slab;
   if (r1 > M) r1 = M;
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const floa
 #pragma unroll
   for (int pass = 0; pass < TPG; ++pass) {
     na[pass] = n0 + T_COLS * pass + 4 * cg;
-    if (na[pass] + 4 > N) na[pass] = N - 4;
+    if (na[pass] + 4 > ncap) na[pass] = ncap - 4;
   }
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -788,7 +789,7 @@ __global__ __launch_bounds__(G6_THREADS, HOTK_G6_WGS) void k_gemm6_tn(const floa
   for (int d = 0; d < DEPTH; ++d) g6_wait_tn(ring[d]);
   float* P = partial + slab * (int64_t)K * N;
   const bool full = (N & 3) == 0 && ((uintptr_t)partial & 15) == 0;
-  g6_store_tile(P, N, k0 + 32 * TM * wm, K - (k0 + 32 * TM * wm), n0 + 32 * TN * wn, N - (n0 + 32 * TN * wn), nullptr, lds, wave,
+  g6_store_tile(P, N, k0 + 32 * TM * wm, K - (k0 + 32 * TM * wm), n0 + 32 * TN * wn, ncap - (n0 + 32 * TN * wn), nullptr, lds, wave,
                 lane, acc, full);
 }
 
@@ -800,8 +801,17 @@ static_assert(HOTK_G6_WGS * G6_LDS <= 160 * 1024, "LDS of the workgroups of a CU
 #ifndef HOTK_G6_TN_WGS
 #define HOTK_G6_TN_WGS 256
 #endif
+// A column tail of at most 128 goes to the 256 x 128 build -- when the wide part is ONE tile column (N = 320, 384): both
+// launches are then a full round of workgroups over the same slabs.  With more wide tiles the tail launch would fill
+// 1 / tiles of the chip for a whole round (256 x 864: 0.76 against 0.70 ms with the tail padded to a fourth 256-tile).
+inline int64_t g6_tn_tail(int64_t N) {
+  const int64_t tail = N % 256;
+  return (tail > 0 && tail <= 128 && N < 512) ? tail : 0;
+}
 int g6_slabs(int64_t M, int64_t K, int64_t N, int64_t* rows_per_slab) {
-  const int64_t tiles = ((K + BM - 1) / BM) * ((N + BN - 1) / BN);
+  // (with a tail, both launches use the slabs of the wide part: each is one full round; a tail alone: its own tiles)
+  const int64_t nw = N - g6_tn_tail(N);
+  const int64_t tiles = ((K + 255) / 256) * (nw > 0 ? (nw + 255) / 256 : 1);
   // one round of workgroups over the 256 CUs (one is resident per CU; a second round that is not full costs a whole
   // round, and every slab costs a K x N partial block written and read again), slabs of at least 1 024 rows (a multiple
   // of the 32-row step)
@@ -833,6 +843,25 @@ int g6_launch_mode(const float* A, int64_t lda, const void* planes, const float*
                      (const uint16_t*)planes, bias, C, ldc, Mt, (int)K, (int)N, (int)tiles_n, (int)col0, (int)ncap, rm);
   return hotk_launch_status();
 }
+// columns [col0, ncap) of the per-slab partial products on this build's tiles: `slabs` slabs of rps rows over Ms rows (or list
+// entries)
+int g6_launch_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t Ms, int64_t K, int64_t N,
+                 int64_t col0, int64_t ncap, int slabs, int64_t rps, const int32_t* rows, hipStream_t st) {
+  const int tiles_k = (int)((K + BM - 1) / BM), tiles_n = (int)((ncap - col0 + BN - 1) / BN);
+  const dim3 grid((unsigned)((int64_t)slabs * tiles_k * tiles_n));
+  if (rows) {
+    static int attr = g6_attr(k_gemm6_tn<true>);
+    if (attr) return attr;
+    hipLaunchKernelGGL(k_gemm6_tn<true>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg, partial, Ms, (int)K, (int)N, tiles_k,
+                       tiles_n, rps, rows, (int)col0, (int)ncap);
+  } else {
+    static int attr = g6_attr(k_gemm6_tn<false>);
+    if (attr) return attr;
+    hipLaunchKernelGGL(k_gemm6_tn<false>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg, partial, Ms, (int)K, (int)N,
+                       tiles_k, tiles_n, rps, rows, (int)col0, (int)ncap);
+  }
+  return hotk_launch_status();
+}
 int g6_launch_nn(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc, int64_t M, int64_t K,
                  int64_t N, int64_t col0, int64_t ncap, const RowMap& rm, hipStream_t st) {
   if (rm.rec) return g6_launch_mode<2>(A, lda, planes, bias, C, ldc, rm.Mc, K, N, col0, ncap, rm, st);
@@ -854,7 +883,16 @@ extern "C" int HOTK_G6_CAT(hotk_gemm6_nn_cols, HOTK_G6_VARIANT)(const float* A, 
                                                                  int64_t col0, int64_t ncap, const void* row_map, void* stream) {
   return g6_launch_nn(A, lda, planes, bias, C, ldc, M, K, N, col0, ncap, *static_cast<const RowMap*>(row_map), (hipStream_t)stream);
 }
+extern "C" int HOTK_G6_CAT(hotk_gemm6_tn_cols, HOTK_G6_VARIANT)(const float* A, int64_t lda, const float* G, int64_t ldg,
+                                                                 float* partial, int64_t Ms, int64_t K, int64_t N, int64_t col0,
+                                                                 int64_t ncap, int slabs, int64_t rps, const int32_t* rows,
+                                                                 void* stream) {
+  return g6_launch_tn(A, lda, G, ldg, partial, Ms, K, N, col0, ncap, slabs, rps, rows, (hipStream_t)stream);
+}
 #else
+extern "C" int hotk_gemm6_tn_cols_n128(const float* A, int64_t lda, const float* G, int64_t ldg, float* partial, int64_t Ms,
+                                       int64_t K, int64_t N, int64_t col0, int64_t ncap, int slabs, int64_t rps,
+                                       const int32_t* rows, void* stream);
 // (row_map: the RowMap of this file, same layout in both builds)
 extern "C" int hotk_gemm6_nn_cols_n128(const float* A, int64_t lda, const void* planes, const float* bias, float* C, int64_t ldc,
                                        int64_t M, int64_t K, int64_t N, int64_t col0, int64_t ncap, const void* row_map,
@@ -931,20 +969,12 @@ int g6_tn(const float* A, int64_t lda, const float* G, int64_t ldg, float* parti
   HOTK_CHECK_ARG(A && G && hotk_aligned16(A) && hotk_aligned16(G) && ((lda | ldg) & 3) == 0);
   int64_t rps;
   const int slabs = g6_slabs(Ms, K, N, &rps);
-  const int tiles_k = (int)((K + BM - 1) / BM), tiles_n = (int)((N + BN - 1) / BN);
-  const dim3 grid((unsigned)((int64_t)slabs * tiles_k * tiles_n));
-  if (rows) {
-    static int attr = g6_attr(k_gemm6_tn<true>);
-    if (attr) return attr;
-    hipLaunchKernelGGL(k_gemm6_tn<true>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg, partial, Ms, (int)K, (int)N, tiles_k,
-                       tiles_n, rps, rows);
-  } else {
-    static int attr = g6_attr(k_gemm6_tn<false>);
-    if (attr) return attr;
-    hipLaunchKernelGGL(k_gemm6_tn<false>, grid, dim3(G6_THREADS), G6_LDS, st, A, lda, G, ldg, partial, Ms, (int)K, (int)N,
-                       tiles_k, tiles_n, rps, rows);
+  const int64_t tail = g6_tn_tail(N), nw = N - tail;
+  if (tail) {
+    const int rc = hotk_gemm6_tn_cols_n128(A, lda, G, ldg, partial, Ms, K, N, nw, N, slabs, rps, rows, st);
+    if (rc || nw == 0) return rc;
   }
-  return hotk_launch_status();
+  return g6_launch_tn(A, lda, G, ldg, partial, Ms, K, N, 0, nw, slabs, rps, rows, st);
 }
 }  // namespace
 

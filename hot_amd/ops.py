@@ -393,15 +393,17 @@ def mm_masks(A, W, rows, trans_w=False, bias=None):
 
 
 def wgrad6_ok(A, B, rows=None):
-    """tall operands whose product fills the 256 x 256 tiles (measured at 254 k rows: [., 512]^T [., 256] 181 against 134
-    TFLOP/s for the library's split-K batch, [., 256]^T [., 864] 166 / 121; below 256 columns on either side the tile is
-    mostly padding: [., 128]^T [., 576] 75 / 118).  The tiles' padded area may exceed K N by a quarter; [., 256]^T [., 320]
-    (1.6) stays with the library even when a row list would skip 30 % of the rows (0.35 against 0.30 ms)."""
+    """tall operands whose product fills the tiles (256 x 256, and 256 x 128 for the tail of N = 320 / 384; measured at
+    254 k rows: [., 512]^T [., 256] 181 against 134 TFLOP/s for the library's split-K batch, [., 256]^T [., 864] 166 / 121;
+    below 256 columns on either side the tile is mostly padding: [., 128]^T [., 576] 75 / 118).  The tiles' padded area
+    may exceed K N by a quarter."""
     K, N = A.size(1), B.size(1)
     if not (_G6 and A.is_cuda and A.dtype == torch.float32 and B.dtype == torch.float32 and A.size(0) >= G6_MIN_ROWS
             and K >= 256 and N >= 256 and K % 4 == 0 and N % 4 == 0):
         return False
-    return -(-K // 256) * -(-N // 256) * 65536 <= 1.25 * K * N
+    tail = N % 256
+    n_pad = (N - tail) + (0 if tail == 0 else 128 if (tail <= 128 and N < 512) else 256)      # (as g6_tn_tail, csrc/gemm6.hip)
+    return -(-K // 256) * 256 * n_pad <= 1.25 * K * N
 
 
 def wgrad6(A, B, rows=None):
@@ -1324,17 +1326,27 @@ class AttnCore22(Function):
         D = w_o.size(0)
         d_out = d_out.contiguous().view(plan.R, D)
         padded = plan.Ev != plan.R
-        dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if padded else d_out
         ve = valid_rows(plan, 'e')
-        datt = thin_gemm(dy, w_o) if thin_wide_ok(plan.R, D, 320) else mm(dy, w_o, rows=ve)
+        use_thin = thin_wide_ok(plan.R, D, 320)
+        use_fused_dwo = _DWO_FUSED and d_out.dtype == torch.float32 and linear_bwd_ok(plan.R, D, 320)
+        # the padding rows of the incoming gradient are zeroed first -- unless nothing below reads them: both products on
+        # the tiled GEMMs over the row list, the bias gradient as a sum by row kind (wide layers: C2)
+        skips_padding = (_L22_SKIP_MASK and padded and ve is not None and not use_thin and not use_fused_dwo
+                         and mm_masks(d_out, w_o, ve) and wgrad6_ok(d_out, att, ve))
+        dy = mask_rows(d_out, plan.kind, KEEP_VALID, 0.0) if (padded and not skips_padding) else d_out
+        datt = thin_gemm(dy, w_o) if use_thin else mm(dy, w_o, rows=ve)
         # att as saved = the (dropped-out) input of fc_o.  dW_o = dy^T . att in the weight-gradient-only mode of
         # hotk_linear_bwd_fused (x = dy, g = att): 3.65 ms against 3.41 ms for the split-K batched GEMM before that
         # kernel's loads were made unconditional, measured again after (profiles/NOTES_r01_r02.md, old section 5)
-        if _DWO_FUSED and dy.dtype == torch.float32 and linear_bwd_ok(plan.R, D, 320):
+        if use_fused_dwo:
             dw_o = linear_bwd_fused(att, dy.contiguous(), None)[1]
         else:
             dw_o = wgrad(dy, att, ve)
-        db_o = dy.sum(0)
+        if skips_padding:
+            db = bias_grads(dy, plan.kind, True, True)
+            db_o = db[0] + db[1]
+        else:
+            db_o = dy.sum(0)
         mu, keep, drop_p = ctx.drop
         AttnCore22._drop_apply(datt, plan, mu, keep, drop_p)
         padded = plan.Ev != plan.R

@@ -218,3 +218,47 @@ def test_projection_redraw_on_device():
         enc(G0)
         seen.append((int(fm.calls_since_last_redraw), torch.equal(fm.projection_matrix, p1)))
     assert seen == [(1, True), (2, True), (0, False)]
+
+
+def test_wide_layers_skip_the_gradient_masks_without_changing_gradients():
+    """At C2's widths and >= 16 k padded rows the dense products run on the tiled GEMMs over the list of valid rows; the
+    backward functions then do not zero the padding rows of the gradients they receive (nothing reads them: ops._l22_backward,
+    ops.AttnCore22.backward).  One EncLayer(2, 2) at D = 256 on 320 molecules: fewer hotk_mask_rows launches, and every
+    gradient equals the masked run's -- bit for bit except fc_o's bias, whose column sum changes its order of addition
+    (by row kind instead of over all rows): 1e-6."""
+    from hot_amd import ops, _lib
+    from hot_amd.batch.sparse import batch_like
+    from hot_amd.models.encoder import EncLayer
+    from hot_amd.models.common import KernelFeatureMap
+    DH = 256
+    nfs, eis, efs, g = _molecules(320, 5, DH)
+    G = _to_dev(nfs, eis, efs)
+    plan = G.plan
+    assert plan.R >= ops.G6_MIN_ROWS and plan.Ev < plan.R
+    torch.manual_seed(0)
+    layer = EncLayer(2, 2, DH, 32, 32, DH, 4, 'default', 'generalized_kernel', 0., 0., KernelFeatureMap(8, generalized_attention=True)).to(DEV)
+    params = dict(layer.named_parameters())
+    Wout = torch.randn(G.values.shape, generator=g).to(DEV)
+
+    def run(skip):
+        ops._L22_SKIP_MASK = skip
+        try:
+            x = G.values.detach().clone().requires_grad_(True)
+            _lib.timing_begin(None)
+            (layer(batch_like(G, x, skip_masking=True)).values * Wout).sum().backward()
+            ran = _lib.timing_end()
+            grads = {'x': x.grad.clone()}
+            for n, p_ in params.items():
+                grads[n] = p_.grad.clone()
+                p_.grad = None
+            return ran.get('hotk_mask_rows', (0., 0, 0))[1], grads
+        finally:
+            ops._L22_SKIP_MASK = True
+    n_off, g_off = run(False)
+    n_on, g_on = run(True)
+    assert n_on <= n_off - 4, (n_on, n_off)            # fc_2 of the attention, both FFN linears, the core's output gradient
+    for n in g_on:
+        if n == 'attn.fc_o.bias':
+            assert rel_err(g_on[n].cpu(), g_off[n].cpu()) < 1e-6
+        else:
+            assert torch.equal(g_on[n], g_off[n]), n
