@@ -1138,3 +1138,31 @@ def test_linear22_light_wide_entry_gemm_epilogue(D, C, with_bias):
     assert ('hotk_mask_rows' not in ran_on) == ((D, C) != (160, 320)) and 'hotk_mask_rows' in ran_off
     for a, b in zip(g_on, g_off):
         assert torch.isfinite(a).all() and torch.equal(a, b)
+
+
+def test_linear22_light_wide_entry_gemm_without_padding():
+    """hotk_gemm6_entry22 on a batch WITHOUT padding rows (every graph the same size): the records then list every row;
+    same numbers as the tiled GEMM + hotk_assemble22, bit for bit."""
+    _lib, ops, make_batch, *_ = _product()
+    from hot_amd.batch.sparse import make_batch_concatenated
+    D, C, n = 256, 256, 6
+    e = np.array(sorted((i, j) for i in range(n) for j in range(n) if i != j and (i + j) % 3), dtype=np.int64).T
+    B = 1200
+    ei = torch.from_numpy(np.concatenate([e] * B, axis=1)).to(DEV)
+    g = torch.Generator().manual_seed(2)
+    G = make_batch_concatenated(torch.randn(B * n, D // 2, generator=g).to(DEV), ei,
+                                torch.randn(B * e.shape[1], D // 2, generator=g).to(DEV), [n] * B, [e.shape[1]] * B)
+    plan = G.plan
+    assert plan.Ev == plan.R >= ops.G6_MIN_ROWS and ops.valid_rows(plan, 'e') is None
+    W = (torch.randn(5 * D, C, generator=g) / D ** 0.5).to(DEV)
+    b_off, b_diag = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
+    x = G.values.reshape(plan.R, D)
+    _lib.timing_begin(None)
+    y1, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+    assert 'hotk_gemm6_entry22' in _lib.timing_end()
+    ops._G6_ENTRY = False
+    try:
+        y2, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+    finally:
+        ops._G6_ENTRY = True
+    assert torch.equal(y1, y2) and torch.isfinite(y1).all()
