@@ -757,9 +757,10 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     db_diag = db_off = None
     # (not when the node-level weight gradient runs on the tiled GEMM: a 257th row would cost it a whole second row of tiles)
     ones_row = want_dw and (has_b[0] or has_b[1]) and not wgrad6_ok(xd, dyn, vn)
-    if not ones_row:
-        db_diag = dyn[:, 0:C].sum(0) if has_b[1] else None
-        db_off = dyn[:, C:2 * C].sum(0) if has_b[0] else None
+    if not ones_row and (has_b[0] or has_b[1]):
+        db = dyn[:, 0:2 * C].sum(0)      # (one pass over both column blocks)
+        db_diag = db[0:C] if has_b[1] else None
+        db_off = db[C:2 * C] if has_b[0] else None
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
     dx = dW = None
     if want_dx:
