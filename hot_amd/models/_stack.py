@@ -32,8 +32,9 @@ def dense_layout():
     from .dense.linear import Linear
     from .dense.f import Apply, Nonlinear, Add
     from .dense.kernelattn import KernelSelfAttn
+    from .dense.attn import SelfAttn
     from ..batch.dense import Batch
-    return Layout('dense', Linear, Apply, Nonlinear, Add, KernelSelfAttn, None, Batch)
+    return Layout('dense', Linear, Apply, Nonlinear, Add, KernelSelfAttn, SelfAttn, Batch)
 
 
 def layout_of(sparse: bool) -> Layout:

@@ -4,7 +4,8 @@ Interface contract (constructor arguments, attribute names -> state_dict keys, f
 hot_pytorch/models/encoder.py:20-96; the assembly is table-driven (models/_stack.py).  Built here: kernel attention
 (att_cfg 'kernel' / 'generalized_kernel') for output orders >= 1 and, as in the reference (encoder.py:34-35), the softmax
 readout SelfAttn(., 0) for an order-0 output, which is linear in |E|.  Quadratic softmax attention for output orders >= 1
-(att_cfg='default') and the order-0 readout in the dense layout are outside the linear-cost path: NotImplementedError."""
+(att_cfg='default') is outside the linear-cost path: NotImplementedError.  The dense layout has the same readout
+(models/dense/attn.py)."""
 import torch.nn as nn
 
 from . import _stack
@@ -40,7 +41,7 @@ class EncLayer(nn.Module):
         # swapped inside; checkpoints depend on it.
         if ord_out == 0:
             if lay.readout_attn is None:
-                raise NotImplementedError('the order-0 softmax readout is built for the sparse layout only')
+                raise NotImplementedError(f'no order-0 softmax readout in the {lay.name} layout')
             return lay.readout_attn(ord_in, 0, dim_in, dim_qk, dim_v, n_heads, cfg, dropout, drop_mu)
         if att_cfg == 'default':
             raise NotImplementedError('softmax SelfAttn with an order >= 1 output is quadratic in |E| and not part of '

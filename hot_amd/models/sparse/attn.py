@@ -16,8 +16,11 @@ from .linear import Linear
 
 
 class SelfAttn(nn.Module):
+    linear_cls = Linear      # (the dense layout's readout, models/dense/attn.py, builds on its own Linear)
+
     def __init__(self, ord_in, ord_out, dim_in, dim_v, dim_qk, n_heads, cfg='default', dropout=0., drop_mu=0.):
         super().__init__()
+        Linear = self.linear_cls
         assert cfg in ('default', 'local')
         self.is_local = cfg == 'local'
         self.ord_in, self.ord_out = ord_in, ord_out

@@ -398,8 +398,46 @@ def dump_dense(name, n_nodes, N, D, dqk, dv, H, dff, seed):
     np.savez_compressed(os.path.join(HERE, name), **out)
 
 
+def dump_dense_readout(name, n_nodes, N, D, dqk, dv, H, dff, seed):
+    """the order-0 softmax readout in the DENSE layout (models/dense/attn.py:84-98,138-157 with attncoef.py:22-59): SelfAttn
+    1->0 and 2->0 on ragged [B,N,D] / [B,N,N,D] batches, and a whole Encoder(2, 0, [2], ..., sparse=False) whose last layer
+    is that readout (encoder.py:34-35)."""
+    from hot_pytorch.batch import dense as DB
+    from hot_pytorch.models.dense.attn import SelfAttn as DSelfAttn
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    B = len(n_nodes)
+    x1 = torch.randn(B, N, D, generator=g)
+    x2 = torch.randn(B, N, N, D, generator=g)
+    out = {'x1': npy(x1), 'x2': npy(x2), 'n_nodes': np.array(n_nodes), 'dims': np.array([N, D, dqk, dv, H, dff])}
+
+    def run(tag, mod, order):
+        for n_, p in mod.named_parameters():
+            if 'bias' in n_ and p.dim() == 1:
+                torch.nn.init.normal_(p, std=0.1)
+        x = (x1 if order == 1 else x2).clone().requires_grad_(True)
+        y = mod(DB.Batch(x, n_nodes))
+        R = torch.randn(y.shape, generator=g)
+        (y * R).sum().backward()
+        for k_, v in mod.state_dict().items():
+            out[f'{tag}/sd/{k_}'] = npy(v)
+        for k_, p in mod.named_parameters():
+            out[f'{tag}/grad/{k_}'] = npy(p.grad)
+        out[f'{tag}/y'] = npy(y); out[f'{tag}/R'] = npy(R); out[f'{tag}/gx'] = npy(x.grad)
+
+    run('att10', DSelfAttn(1, 0, D, dv, dqk, H), 1)
+    run('att20', DSelfAttn(2, 0, D, dv, dqk, H), 2)
+    enc = Encoder(2, 0, [2], D, 3, 16, dqk, dv, dff, H, dqk, dv, H, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
+    enc.skip_redraw_projections = True
+    run('enc20', enc, 2)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
 def main():
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == 'dense_readout':
+        dump_dense_readout('dense_readout.npz', [5, 3, 4, 1], N=5, D=4, dqk=8, dv=8, H=2, dff=12, seed=91)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == 'dense':
         dump_dense('dense_small.npz', [5, 3, 4], N=5, D=4, dqk=8, dv=8, H=2, dff=12, seed=81)
         dump_dense('dense_c3.npz', [20, 20], N=20, D=2, dqk=32, dv=32, H=4, dff=32, seed=82)

@@ -120,3 +120,32 @@ def test_dense_set_to_graph_c3_shape():
     yp = enc(DB.Batch(x[:, perm].clone(), n_nodes[:-1] + [N])).A      # full sets only: a permutation moves padding
     y0 = enc(DB.Batch(x.clone(), n_nodes[:-1] + [N])).A
     assert rel_err(yp.detach().cpu(), y0[:, perm][:, :, perm].detach().cpu()) < 1e-4
+
+
+def test_dense_readout_vs_reference():
+    """the order-0 softmax readout in the dense layout (models/dense/attn.py: SelfAttn 1 -> 0 and 2 -> 0, and an
+    Encoder(2, 0, [2], ..., sparse=False) that ends in it) against the reference's dense modules
+    (tests/golden/make_golden.py dense_readout): ragged n_nodes incl. a one-node graph (no off-diagonal entry: the
+    graph -> vector term is an empty softmax there), outputs and every gradient."""
+    from hot_amd.batch import dense as DB
+    from hot_amd.models.dense.attn import SelfAttn
+    from hot_amd.models.encoder import Encoder
+    z = load_golden('dense_readout.npz')
+    N, D, dqk, dv, H, dff = [int(v) for v in z['dims']]
+    n_nodes = [int(v) for v in z['n_nodes']]
+    x1, x2 = tt(z['x1']).to(DEV), tt(z['x2']).to(DEV)
+
+    def run(tag, mod, order):
+        mod = _load_layer(mod, z, tag)
+        x = (x1 if order == 1 else x2).clone().requires_grad_(True)
+        y = mod(DB.Batch(x, n_nodes))
+        assert isinstance(y, torch.Tensor) and rel_err(y.detach().cpu(), z[f'{tag}/y']) < TOL, tag
+        (y * tt(z[f'{tag}/R']).to(DEV)).sum().backward()
+        assert rel_err(x.grad.cpu(), z[f'{tag}/gx']) < 2 * TOL, tag
+        _check_param_grads(mod, z, f'{tag}/grad/')
+
+    run('att10', SelfAttn(1, 0, D, dv, dqk, H), 1)
+    run('att20', SelfAttn(2, 0, D, dv, dqk, H), 2)
+    enc = Encoder(2, 0, [2], D, 3, 16, dqk, dv, dff, H, dqk, dv, H, 'default', 'generalized_kernel', 0., 0., 0., sparse=False)
+    enc.skip_redraw_projections = True
+    run('enc20', enc, 2)
