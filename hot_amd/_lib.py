@@ -79,6 +79,7 @@ STORAGE_F32, STORAGE_BF16 = 0, 1
 
 # phases of hotk_attn22_phase (include/hotk.h)
 ATTN22_FWD_GRAPHSUM, ATTN22_FWD_NODESUM, ATTN22_FWD_APPLY, ATTN22_BWD_QUERY, ATTN22_BWD_KEYVAL = range(5)
+ATTN22_FWD_APPLY_GRAPH, ATTN22_FWD_APPLY_NODE, ATTN22_BWD_KEYVAL_GRAPH, ATTN22_BWD_KEYVAL_NODE = range(5, 9)
 
 
 _SIGNATURES.update({

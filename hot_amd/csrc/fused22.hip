@@ -1871,7 +1871,7 @@ extern "C" int hotk_attn22_backward(const hotk_attn22_args* a, void* workspace, 
 extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* workspace, size_t ws_bytes, void* stream) {
   int rc = check_args(a);
   if (rc) return rc;
-  HOTK_CHECK_ARG(phase >= HOTK_ATTN22_FWD_GRAPHSUM && phase <= HOTK_ATTN22_BWD_KEYVAL);
+  HOTK_CHECK_ARG(phase >= HOTK_ATTN22_FWD_GRAPHSUM && phase <= HOTK_ATTN22_BWD_KEYVAL_NODE);
   if (a->storage != HOTK_STORAGE_F32) return HOTK_EUNSUPPORTED;   // the sums exchanged between the phases are fp32 tables
   HOTK_CHECK_ARG(a->kvg && a->kvn && a->nd0 && hotk_aligned16(a->kvn) && a->diag_w > 0.f);
   if (a->R == 0 || a->Nn == 0) return HOTK_OK;
@@ -1899,18 +1899,26 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
       hipLaunchKernelGGL(k_seg_kvsum<1>, gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
       hipLaunchKernelGGL(k_seg_kvsum<2>, gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
       break;
-    case HOTK_ATTN22_FWD_APPLY: {
+    case HOTK_ATTN22_FWD_APPLY:
+    case HOTK_ATTN22_FWD_APPLY_GRAPH:
+    case HOTK_ATTN22_FWD_APPLY_NODE: {
       HOTK_CHECK_ARG(a->att && a->ld_att >= 10 * SLOT && (a->ld_att & 3) == 0 && hotk_aligned16(a->att));
-      const int64_t per = 16 * GA_TILES;
-      const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
-      hipLaunchKernelGGL(k_graph_apply_fwd_t<float>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, (unsigned*)nullptr);
-      hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
-      hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
-      hipLaunchKernelGGL(k_node_apply_nd, gseg, dim3(TPB), 0, st, *a);
+      if (phase != HOTK_ATTN22_FWD_APPLY_NODE) {      // terms 7-10: per-graph sums only (kvg)
+        const int64_t per = 16 * GA_TILES;
+        const int64_t nga = a->B * ((a->Nmax + per - 1) / per + (a->Emax + per - 1) / per);
+        hipLaunchKernelGGL(k_graph_apply_fwd_t<float>, dim3(hotk_grid(nga, WPB, GRID_CAP)), dim3(TPB), 0, st, *a, (unsigned*)nullptr);
+      }
+      if (phase != HOTK_ATTN22_FWD_APPLY_GRAPH) {     // terms 1-6: per-node sums (kvn, nd0)
+        hipLaunchKernelGGL((k_seg_fwd<float, 1, false, true>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+        hipLaunchKernelGGL((k_seg_fwd<float, 2, false, true>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
+        hipLaunchKernelGGL(k_node_apply_nd, gseg, dim3(TPB), 0, st, *a);
+      }
       break;
     }
     case HOTK_ATTN22_BWD_QUERY:
     case HOTK_ATTN22_BWD_KEYVAL:
+    case HOTK_ATTN22_BWD_KEYVAL_GRAPH:
+    case HOTK_ATTN22_BWD_KEYVAL_NODE:
       HOTK_CHECK_ARG(a->dkvn && a->dd0 && hotk_aligned16(a->dkvn) && a->datt && a->dh1 && a->dh2 && a->dv && a->ck && a->dkvg);
       HOTK_CHECK_ARG(a->ld_datt >= 10 * SLOT && a->ld_dh1 >= 12 * SLOT && a->ld_dh2 >= 8 * SLOT + a->D && a->D >= 0 &&
                      a->ld_dv >= 10 * SLOT);
@@ -1924,10 +1932,12 @@ extern "C" int hotk_attn22_phase(const hotk_attn22_args* a, int phase, void* wor
         hipLaunchKernelGGL((k_seg_bwd<float, 2, 1>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
         hipLaunchKernelGGL(k_node_dd, gseg, dim3(TPB), 0, st, *a);
       } else {
-        launch_graphsum_bwd<float>(st, a, nullptr);
-        hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
-        hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
-        hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 0));
+        if (phase != HOTK_ATTN22_BWD_KEYVAL_NODE) launch_graphsum_bwd<float>(st, a, nullptr);      // from dkvg only
+        if (phase != HOTK_ATTN22_BWD_KEYVAL_GRAPH) {                                             // from dkvn / dd0
+          hipLaunchKernelGGL((k_seg_bwd<float, 1, 2>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 1));
+          hipLaunchKernelGGL((k_seg_bwd<float, 2, 2>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 2));
+          hipLaunchKernelGGL((k_seg_bwd<float, 0, 3>), gdyn, dim3(TPB), 0, st, *a, tk_slot(tickets, 0));
+        }
       }
       break;
   }

@@ -81,6 +81,14 @@ def max_over_ranks(value: float, device, group=None) -> float:
     return float(t.item())
 
 
+class _Done:
+    """handle of a collective that has already completed"""
+
+    @staticmethod
+    def wait():
+        return True
+
+
 class ShardInfo:
     """Edge-shard context attached to a Plan (`plan.shard`): ops that sum over entries all-reduce their summaries."""
 
@@ -92,6 +100,16 @@ class ShardInfo:
         if self.world > 1:
             _all_reduce(t, dist.ReduceOp.SUM, self.group)
         return t
+
+    def all_reduce_start_(self, t: torch.Tensor):
+        """SUM all-reduce of t in place, not waited for: returns a handle whose .wait() orders the current stream behind
+        it.  With RCCL the collective runs on the backend's own stream, so kernels launched between start and wait --
+        which must not touch t -- overlap it (the fused core's per-graph half runs under the per-node sums' exchange:
+        ops.AttnCore22).  A gloo group (host-staged rehearsal) or a world of one completes at once."""
+        if self.world > 1 and t.is_cuda and dist.get_backend(self.group) != 'gloo':
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self.all_reduce_(t)
+        return _Done()
 
     def all_reduce_max_(self, t: torch.Tensor) -> torch.Tensor:
         if self.world > 1:

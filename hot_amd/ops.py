@@ -1294,8 +1294,12 @@ class AttnCore22(Function):
             AttnCore22._phase(a, _lib.ATTN22_FWD_GRAPHSUM, ws, nws, 4 * plan.Ev * 4 * 32)
             AttnCore22._reduce_entry_slots(shard, kvg)
             AttnCore22._phase(a, _lib.ATTN22_FWD_NODESUM, ws, nws, 4 * plan.Ev * 6 * 32 + 4 * kvn.numel())
-            shard.all_reduce_(kvn[P1:])
-            AttnCore22._phase(a, _lib.ATTN22_FWD_APPLY, ws, nws, 4 * plan.Ev * (6 * 32 + 10 * 32) + 4 * kvn.numel())
+            # the exchange of the per-node sums (the large one: 2 432 floats per node) runs under the half of the
+            # application that needs the per-graph sums only
+            pending = shard.all_reduce_start_(kvn[P1:])
+            AttnCore22._phase(a, _lib.ATTN22_FWD_APPLY_GRAPH, ws, nws, 4 * plan.Ev * (2 * 32 + 4 * 32))
+            pending.wait()
+            AttnCore22._phase(a, _lib.ATTN22_FWD_APPLY_NODE, ws, nws, 4 * plan.Ev * (4 * 32 + 6 * 32) + 4 * kvn.numel())
         # training-mode MuDropout / Dropout act on the concatenated terms, outside the core: the fused kernels stay on
         # the path (the reference's shipped training configs use dropout 0.1, enc-small.sh:3)
         mu, keep = AttnCore22._drop_masks(plan, dev, drop_p, mu_p)
@@ -1389,9 +1393,11 @@ class AttnCore22(Function):
             a.kvn, a.nd0, a.diag_w = kvn.data_ptr(), kvn.data_ptr() + 4 * 3 * P1, 1.0 / shard.world
             a.dkvn, a.dd0 = dkvn.data_ptr(), dkvn.data_ptr() + 4 * 2 * P1
             AttnCore22._phase(a, _lib.ATTN22_BWD_QUERY, ws, nws, 4 * plan.Ev * (6 * 32 * 2 + 10 * 32) + 8 * kvn.numel())
-            AttnCore22._reduce_entry_slots(shard, dkvg)
-            shard.all_reduce_(dkvn)
-            AttnCore22._phase(a, _lib.ATTN22_BWD_KEYVAL, ws, nws, 4 * plan.Ev * (10 * 32 * 2 + 8 * 32 + 2 * 32) + 4 * kvn.numel())
+            AttnCore22._reduce_entry_slots(shard, dkvg)      # (small, and first: the per-graph half below waits for it)
+            pending = shard.all_reduce_start_(dkvn)
+            AttnCore22._phase(a, _lib.ATTN22_BWD_KEYVAL_GRAPH, ws, nws, 4 * plan.Ev * (4 * 32 * 2 + 2 * 32))
+            pending.wait()
+            AttnCore22._phase(a, _lib.ATTN22_BWD_KEYVAL_NODE, ws, nws, 4 * plan.Ev * (6 * 32 * 2 + 6 * 32 + 2 * 32) + 4 * kvn.numel())
         # d(raw key slots 0..5 of node i) = sum over the entries of row i of their per-entry contributions
         seg_sum_rows(ck, plan.row_seg(), None, KEEP_VALID, out=dh1[:, 128:320])
         return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None, None, None

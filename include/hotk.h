@@ -441,9 +441,15 @@ int hotk_seg_sum_rows_bf16(const void* src, int64_t ld_src, const int32_t* seg_b
  *                                                                       -> all-reduce dkvg slots 1 and 3, dkvn, dd0
  *   BWD_KEYVAL   : dv, ck, dh2 (key slots, skip path), dh1 (query slots 0, 1 from this rank's partial part-0 sums;
  *                  key slots 10, 11) from dkvg / dkvn / dd0
- * Buffers and shapes as for hotk_attn22_forward / _backward; kvn / dkvn rows of padding nodes are not touched. */
+ * Buffers and shapes as for hotk_attn22_forward / _backward; kvn / dkvn rows of padding nodes are not touched.
+ * FWD_APPLY and BWD_KEYVAL in two halves each, for callers that overlap the large per-node all-reduce with the half that
+ * does not need it: FWD_APPLY_GRAPH (terms 7-10, from kvg) | FWD_APPLY_NODE (terms 1-6, from kvn / nd0);
+ * BWD_KEYVAL_GRAPH (the per-graph key / value side, from dkvg) | BWD_KEYVAL_NODE (the per-node one, from dkvn / dd0).
+ * The halves write disjoint outputs or accumulate in a fixed order: same results as the whole phase. */
 enum { HOTK_ATTN22_FWD_GRAPHSUM = 0, HOTK_ATTN22_FWD_NODESUM = 1, HOTK_ATTN22_FWD_APPLY = 2,
-       HOTK_ATTN22_BWD_QUERY = 3, HOTK_ATTN22_BWD_KEYVAL = 4 };
+       HOTK_ATTN22_BWD_QUERY = 3, HOTK_ATTN22_BWD_KEYVAL = 4,
+       HOTK_ATTN22_FWD_APPLY_GRAPH = 5, HOTK_ATTN22_FWD_APPLY_NODE = 6,
+       HOTK_ATTN22_BWD_KEYVAL_GRAPH = 7, HOTK_ATTN22_BWD_KEYVAL_NODE = 8 };
 int hotk_attn22_phase(const hotk_attn22_args* args, int phase, void* workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
