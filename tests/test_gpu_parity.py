@@ -1166,3 +1166,44 @@ def test_linear22_light_wide_entry_gemm_without_padding():
     finally:
         ops._G6_ENTRY = True
     assert torch.equal(y1, y2) and torch.isfinite(y1).all()
+
+
+@pytest.mark.parametrize('M,K,N', [(1, 32, 4), (255, 64, 100), (257, 32, 130), (300, 96, 257), (1000, 160, 64)])
+def test_gemm6_abi_small_and_odd_shapes(M, K, N):
+    """hotk_gemm6_* called through the C ABI at sizes the Python wrappers never send it (they keep small products on the
+    library): one row, row counts around the 256-row tile, column counts that are not a multiple of four (the
+    element-wise store path) or just past a tile, an unaligned bias; the row-list form refuses what it cannot store as
+    16-byte pieces (HOTK_EUNSUPPORTED), and a row list on the aligned shapes gives mask(A W + b)."""
+    _lib, ops, *_ = _product()
+    from hot_amd._lib import lib, p, call, stream_ptr
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A = torch.randn(M, K, generator=g).to(DEV)
+    W = (torch.randn(K, N, generator=g) / K ** 0.5).to(DEV)
+    bias_store = torch.randn(N + 1, generator=g).to(DEV)
+    planes = torch.empty(3, N, K, dtype=torch.bfloat16, device=DEV)
+    call('hotk_gemm6_split_weight', 0, p(W), N, K, N, 1, p(planes))
+    ref = A.double() @ W.double()
+    for bias in (None, bias_store[:N], bias_store[1:]):          # the last one: 4 bytes off a 16-byte boundary
+        C = torch.full((M, N), float('nan'), device=DEV)
+        call('hotk_gemm6_nn', 0, p(A), K, p(planes), p(bias), p(C), N, M, K, N)
+        want = ref if bias is None else ref + bias.double()
+        assert rel_err(C.cpu(), want.cpu()) < 2e-6
+    # weight gradient (K, N multiples of four only)
+    if N % 4 == 0:
+        G = torch.randn(M, N, generator=g).to(DEV)
+        n = ctypes.c_int64()
+        assert lib().hotk_gemm6_tn_partials(M, K, N, ctypes.byref(n)) == 0
+        part = torch.full((n.value, K, N), float('nan'), device=DEV)
+        call('hotk_gemm6_tn', 0, p(A), K, p(G), N, p(part), M, K, N)
+        assert rel_err(part.sum(0).cpu(), (A.double().t() @ G.double()).cpu()) < 2e-6
+    # row list
+    keep = torch.rand(M, generator=g) < 0.6
+    rows = torch.nonzero(keep).view(-1).to(torch.int32).to(DEV)
+    C = torch.full((M, N), float('nan'), device=DEV)
+    rc = lib().hotk_gemm6_nn_rows(p(A), K, p(planes), p(bias_store[:N]), p(C), N, M, K, N, p(rows), rows.numel(), stream_ptr())
+    if N % 4 or rows.numel() == 0:
+        assert rc != 0 or rows.numel() == 0
+    else:
+        assert rc == 0
+        want = torch.where(keep.to(DEV)[:, None], ref + bias_store[:N].double(), torch.zeros_like(ref))
+        assert rel_err(C.cpu(), want.cpu()) < 2e-6 and float(C[~keep.to(DEV)].abs().max() if (~keep).any() else 0.) == 0.0
