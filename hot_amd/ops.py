@@ -731,6 +731,18 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
     return y, xd, x2
 
 
+_L22_REDUCE = os.environ.get('HOTK_L22_REDUCE', '1') == '1'      # (A/B switch)
+
+
+def l22_reduce_ok(g, x2, plan):
+    """the one-pass entry-level reductions of the light basis' backward (hotk_linear22_bwd_reduce) cover this batch: a
+    sparse plan with its graphs' rows side by side (not an edge shard, whose sums are all-reduced elsewhere), fp32, the
+    headline widths"""
+    return (_L22_REDUCE and g.dtype == torch.float32 and x2.dtype == torch.float32 and n_rows(g) >= THIN_MIN_ROWS
+            and type(plan).__name__ == 'Plan' and getattr(plan, 'shard', None) is None and plan.R < (1 << 31)
+            and lib().hotk_linear22_bwd_reduce_supported(int(x2.size(1)), int(g.size(1)), int(plan.Nmax)) == 1)
+
+
 def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_extra=None, dx_add=None):
     """gradients of the factored Linear(2, 2, 'light') from g = dy [R, C] -> (dx [R, D], dW [5D, C], db_off, db_diag).
     dxd_extra [Nn, D]: another gradient of the diagonal input rows (fc_1's), dx_add [R, D]: another gradient of all input
@@ -749,8 +761,19 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
     # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
     dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
-    call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-    seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
+    dW2 = None
+    if l22_reduce_ok(g, x2, plan):
+        # one pass over g for the three node blocks AND the entry-level weight gradient (csrc/l22bwd.hip)
+        n = ctypes_long()
+        check(lib().hotk_linear22_bwd_reduce_partials(plan.B, byref(n)), 'hotk_linear22_bwd_reduce_partials')
+        part = torch.empty(n.value, 2 * D, C, dtype=g.dtype, device=dev)
+        call('hotk_linear22_bwd_reduce', 4 * plan.Ev * (C + 2 * D) + 12 * plan.Nn * C, p(g), C, p(x2), 2 * D, 2 * D, C,
+             p(plan.kind), p(plan.rown), p(plan.coln), p(plan.g_ebeg), p(plan.g_eend), p(plan.n_nodes_dev), plan.B,
+             plan.Nmax, plan.R, p(dyn), 3 * C, p(part))
+        dW2 = part[0] if n.value == 1 else part.sum(0)
+    else:
+        call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
+        seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
     # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
     # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows -- and
     # those column sums are one more row of the node-level weight gradient: [xd | 1]^T . dyn (no pass of their own)
@@ -784,7 +807,7 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
             dWn = dWn[:D]
         else:
             dWn = wgrad(xd, dyn, vn)
-        dW = torch.cat([dWn[:, 0:C], wgrad(x2, g, ve), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
+        dW = torch.cat([dWn[:, 0:C], dW2 if dW2 is not None else wgrad(x2, g, ve), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
     return dx, dW, db_off, db_diag
 
 

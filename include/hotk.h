@@ -283,6 +283,23 @@ int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);
 int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K, int64_t C,
                           float* dx, int64_t lddx, float* partial, int64_t R, void* stream);
 
+/* Entry-level reductions of the backward pass of the factored Linear(2, 2, 'light') (models/sparse/linear.py:143-161,
+ * 293-306 under autograd: the scatter_add_ of the diagonal / row / column gathers and the weight gradient of the entry
+ * blocks) in ONE pass over g = dy [R, C], graph by graph:
+ *   dyn[v][0..C) = g at the diagonal entry (v, v);  dyn[v][C..2C) / [2C..3C) = sums of g over the off-diagonal entries of
+ *   row / column v;  partial[n][K2][C] = per-workgroup parts of x2^T @ g (x2 = [x_ij | x_ji] [R, K2], zero on diagonal
+ *   rows), summed by the caller in order (n = hotk_linear22_bwd_reduce_partials(B)).
+ * All as bf16 matrix-core products on the exact three-way split of g (the sums against one-hot operands): fp32-exact
+ * (2e-7), no atomics, bitwise reproducible.  Rows of graph b are [g_ebeg[b], g_eend[b]); node rows b * Nmax + local id;
+ * n_nodes[b] nodes are real, the other node rows of dyn leave as zeros.  Every dyn row is written.  Shapes: K2 = 64,
+ * C = 288, Nmax <= 64 (hotk_linear22_bwd_reduce_supported), others HOTK_EUNSUPPORTED.  g rows 16-byte aligned. */
+int hotk_linear22_bwd_reduce_supported(int64_t K2, int64_t C, int64_t Nmax);
+int hotk_linear22_bwd_reduce_partials(int64_t B, int64_t* n_partials);
+int hotk_linear22_bwd_reduce(const float* g, int64_t ldg, const float* x2, int64_t ld_x2, int64_t K2, int64_t C,
+                             const uint8_t* kind, const int32_t* rown, const int32_t* coln, const int32_t* g_ebeg,
+                             const int32_t* g_eend, const int32_t* n_nodes, int64_t B, int64_t Nmax, int64_t R, float* dyn,
+                             int64_t ld_dyn, float* partial, void* stream);
+
 /* Wide dense projections as fp32-exact tiled GEMMs on the bf16 matrix pipe (csrc/gemm6.hip): every fp32 operand is split
  * exactly into three bf16 numbers and the six products of relative weight >= 2^-16 are summed in fp32 (1.8e-7 against
  * fp64, as the library's fp32 GEMM).  replaces the aten mm / addmm calls under nn.Linear and _Weight.get_output for the
