@@ -110,6 +110,12 @@ __device__ __forceinline__ void rb_glds16(const void* gsrc, uint32_t lds_dst) {
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same from a wave-uniform base and a 32-bit byte offset per lane (no 64-bit address arithmetic in vector registers)
+__device__ __forceinline__ void rb_glds16s(const void* sbase, uint32_t voff, uint32_t lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ __forceinline__ void rb_glds4(const void* gsrc, uint32_t lds_dst) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
@@ -167,29 +173,33 @@ __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const i
   auto issue = [&](const Tile& t, int s3, int s2) __attribute__((always_inline)) {
     const bool ok = t.b < a.B;
     const int64_t r0 = ok ? t.r0 : 0, e1 = ok ? t.e1 : 1;
-    const int64_t dead = e1 > 0 ? e1 - 1 : 0;          // rows past the graph's end re-read its last row (zeroed after landing)
+    // Addresses = a wave-uniform row base (scalar arithmetic) + a 32-bit lane offset.  Rows past the graph's end re-read the
+    // base row (zeroed after landing); a graph without rows reads the row before it (or row 0).
+    const int64_t rb = r0 < e1 ? r0 : (e1 > 0 ? e1 - 1 : 0);
+    const int nlive = (int)(e1 - r0 < 32 ? (e1 > r0 ? e1 - r0 : 0) : 32);      // live rows of the tile
     if (frag >= 0) {
       const int kg = frag >> 1, mt = frag & 1;
+      const float* xb = a.X2 + rb * a.ldx + 32 * mt;
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
-        const int64_t row = r0 + 16 * kg + 8 * q + lr;
-        const int64_t rc = row < e1 ? row : dead;
-        rb_glds16(a.X2 + rc * a.ldx + 32 * mt + lc, lds0 + RB_OFF_XRAW + ((s2 * 4 + frag) * 2 + q) * 1024);
+        const int rl = 16 * kg + 8 * q + lr;
+        const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldx + lc) * 4);
+        rb_glds16s(xb, off, lds0 + RB_OFF_XRAW + ((s2 * 4 + frag) * 2 + q) * 1024);
       }
     } else if (meta_wave) {
-      const int64_t row = r0 + j;
-      const int64_t rc = row < e1 ? row : dead;
+      const int64_t rc = j < nlive ? rb + j : rb;
       rb_glds4((half ? a.coln : a.rown) + rc, lds0 + RB_OFF_MRAW + s2 * 256);
     }
+    const float* gb_ = a.G + rb * a.ldg + col0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int64_t row = r0 + 8 * i + lr;
+      const int rl = 8 * i + lr;
 #ifdef RB_PROBE_NOLOAD
-      const int64_t rc = 8 * i + lr + 0 * (row + dead);
+      const uint32_t off = (uint32_t)((rl * 0 + lc) * 4);
 #else
-      const int64_t rc = row < e1 ? row : dead;
+      const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldg + lc) * 4);
 #endif
-      rb_glds16(a.G + rc * a.ldg + col0 + lc, lds0 + s3 * RB_G_STAGE + (wave * 4 + i) * 1024);
+      rb_glds16s(gb_, off, lds0 + s3 * RB_G_STAGE + (wave * 4 + i) * 1024);
     }
   };
   // "the raw operands of the tile before the youngest two are in LDS" / "the g piece ..." for this wave's load count
