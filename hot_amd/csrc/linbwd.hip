@@ -331,7 +331,27 @@ int lb_launch(const float* G, int64_t ldg, const float* X, int64_t ldx, const fl
 
 }  // namespace
 
-extern "C" int hotk_linear_bwd_supported(int64_t K, int64_t C) { return (K == LB_K && (C == 320 || C == 64)) ? 1 : 0; }
+namespace {
+// one launch over the chunks [c_lo, c_lo + 32 nch) of g / W
+template <bool WANT_DX>
+int lb_launch_n(int nch, const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
+                float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
+  switch (nch) {
+    case 1: return lb_launch<1, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 2: return lb_launch<2, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 3: return lb_launch<3, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 4: return lb_launch<4, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    default: return lb_launch<5, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+  }
+}
+constexpr int LB_MAX_C = 1024;
+}  // namespace
+
+// K = 32 and any width that is a multiple of 32 up to 1 024: launches of at most five 32-column chunks side by side (every
+// byte of g is read once; dx, 32 floats per row, is re-read and added to by each launch after the first)
+extern "C" int hotk_linear_bwd_supported(int64_t K, int64_t C) {
+  return (K == LB_K && C >= 32 && C <= LB_MAX_C && C % 32 == 0) ? 1 : 0;
+}
 
 extern "C" int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials) {
   HOTK_CHECK_ARG(n_partials && R >= 0);
@@ -352,16 +372,15 @@ extern "C" int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x
                ? HOTK_OK : HOTK_ELAUNCH;
   }
   hipStream_t st = (hipStream_t)stream;
-  if (!dx) {   // weight / bias gradients only (W is not read)
-    if (C == 320) {
-      const int rc = lb_launch<5, false>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 320, 0, st);
-      return rc ? rc : lb_launch<5, false>(g, ldg, x, ldx, W, dx, lddx, partial, R, 160, 320, 0, st);
-    }
-    return lb_launch<2, false>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 64, 0, st);
+  // chunk groups of equal size where the width allows it (C = 320: two launches of five; 864 = 27 chunks: 5 5 5 4 4 4)
+  const int chunks = (int)(C / 32), launches = (chunks + 4) / 5;
+  int c_lo = 0;
+  for (int l = 0; l < launches; ++l) {
+    const int nch = chunks / launches + (l < chunks % launches ? 1 : 0);
+    const int rc = dx ? lb_launch_n<true>(nch, g, ldg, x, ldx, W, dx, lddx, partial, R, c_lo, (int)C, l > 0 ? 1 : 0, st)
+                      : lb_launch_n<false>(nch, g, ldg, x, ldx, W, dx, lddx, partial, R, c_lo, (int)C, 0, st);
+    if (rc) return rc;
+    c_lo += 32 * nch;
   }
-  if (C == 320) {
-    const int rc = lb_launch<5, true>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 320, 0, st);
-    return rc ? rc : lb_launch<5, true>(g, ldg, x, ldx, W, dx, lddx, partial, R, 160, 320, 1, st);
-  }
-  return lb_launch<2, true>(g, ldg, x, ldx, W, dx, lddx, partial, R, 0, 64, 0, st);
+  return HOTK_OK;
 }

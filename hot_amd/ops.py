@@ -779,17 +779,28 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
     # those column sums are one more row of the node-level weight gradient: [xd | 1]^T . dyn (no pass of their own)
     db_diag = db_off = None
     # (not when the node-level weight gradient runs on the tiled GEMM: a 257th row would cost it a whole second row of tiles)
-    ones_row = want_dw and (has_b[0] or has_b[1]) and not wgrad6_ok(xd, dyn, vn)
-    if not ones_row and (has_b[0] or has_b[1]):
+    # narrow node input, wide node gradient (the headline widths): data gradient, weight gradient and the column sums
+    # (= both bias gradients) from ONE pass over dyn [Nn, 3C] (hotk_linear_bwd_fused) instead of three
+    node_fused = want_dx and want_dw and dyn.dtype == torch.float32 and linear_bwd_ok(plan.Nn, D, 3 * C)
+    ones_row = want_dw and (has_b[0] or has_b[1]) and not node_fused and not wgrad6_ok(xd, dyn, vn)
+    if not ones_row and not node_fused and (has_b[0] or has_b[1]):
         db = dyn[:, 0:2 * C].sum(0)      # (one pass over both column blocks)
         db_diag = db[0:C] if has_b[1] else None
         db_off = db[C:2 * C] if has_b[0] else None
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
     dx = dW = None
-    if want_dx:
-        dxd = mm(dyn, Wn, trans_w=True, rows=vn)
+    dWn = None
+    if node_fused:
+        dxd, dWn, dbn = linear_bwd_fused(dyn, xd, Wn)
+        db_diag = dbn[0:C] if has_b[1] else None
+        db_off = dbn[C:2 * C] if has_b[0] else None
         if dxd_extra is not None:
             dxd += dxd_extra
+    if want_dx:
+        if dWn is None:
+            dxd = mm(dyn, Wn, trans_w=True, rows=vn)
+            if dxd_extra is not None:
+                dxd += dxd_extra
         # wide-input data gradient [R, C] x [C, 2D]: the thin kernel's row stream since its two-register-set form
         # (same-box A/B at 10 M rows, C = 288 -> 64: 3.08 ms against 3.46 ms for the library GEMM)
         dx2 = thin_gemm(g, W[D:3 * D].t()) if (g.dtype == torch.float32 and thin_ok(n_rows(g), C, 2 * D)) else mm(g, W[D:3 * D], trans_w=True, rows=ve)
@@ -797,7 +808,9 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
     if want_dw:
-        if ones_row:
+        if dWn is not None:
+            pass
+        elif ones_row:
             # (the ones column padded to four: rows of [xd | 1 0 0 0] stay 16-byte aligned for the tiled weight-gradient GEMM)
             one = torch.zeros(xd.size(0), 4, dtype=xd.dtype, device=dev)
             one[:, 0] = 1.
@@ -883,10 +896,15 @@ class Proj22(Function):
         g1 = dh1.contiguous().view(plan.Nn, -1)
         if ctx.nodes_padded:
             g1 = mask_rows(g1, plan.nkind, KEEP_VALID, 0.0)
-        db1 = bias_grads(g1, plan.nkind, False, True)[1] if ctx.has_b[0] else None
         vn = valid_rows(plan, 'n')
-        dW1 = wgrad(xd, g1, vn)
-        dxd1 = mm(g1, W1, trans_w=True, rows=vn)
+        if g1.dtype == torch.float32 and linear_bwd_ok(plan.Nn, xd.size(1), g1.size(1)):
+            dxd1, dW1, db1 = linear_bwd_fused(g1, xd, W1)      # one pass over g1 [Nn, 12 dqk]
+            if not ctx.has_b[0]:
+                db1 = None
+        else:
+            db1 = bias_grads(g1, plan.nkind, False, True)[1] if ctx.has_b[0] else None
+            dW1 = wgrad(xd, g1, vn)
+            dxd1 = mm(g1, W1, trans_w=True, rows=vn)
         # fc_2, with the other two gradients of x folded in
         g2 = dh2.contiguous().view(plan.R, -1)
         dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv)

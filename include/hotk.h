@@ -276,7 +276,8 @@ int hotk_seg_softmax_pool_bwd(const float* q, int64_t ld_q, const float* k, int6
  * aten's addmm backward):  dx[R, K] = g @ W^T;  partial[n][K + 2][C]: per-workgroup partial sums of x^T @ g (rows 0..K-1)
  * and of the column sums of g (rows K, K + 1).  The caller sums the n = hotk_linear_bwd_partials(R) blocks in order:
  * dW = sum[0:K], db = sum[K] + sum[K + 1].  dx = NULL: only the partial sums (W is not read) -- the weight gradient of a
- * wide-INPUT layer y = a @ W^T is the same product with x := dy and g := a (fc_o, kernelattn.py:52).  Shapes: K = 32 and C in {64, 320} (hotk_linear_bwd_supported), others
+ * wide-INPUT layer y = a @ W^T is the same product with x := dy and g := a (fc_o, kernelattn.py:52).  Shapes: K = 32 and C a multiple of 32 up to 1 024 (hotk_linear_bwd_supported; launches of at most
+ * five 32-column chunks side by side: fc_v 320, the node-level products of Linear(2,1/2,'light') 384 / 864), others
  * HOTK_EUNSUPPORTED.  g, x, dx rows 16-byte aligned. */
 int hotk_linear_bwd_supported(int64_t K, int64_t C);
 int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);

@@ -331,11 +331,14 @@ def test_thin_gemm_vs_fp64(K, C):
         assert rel_err(y0.cpu(), (A.double() @ W.double()).float().cpu()) < TOL
 
 
-@pytest.mark.parametrize('R,C', [(70001, 320), (33000, 64), (255, 320)])
+@pytest.mark.parametrize('R,C', [(70001, 320), (33000, 64), (255, 320), (40003, 864), (33001, 384), (1001, 32), (513, 1024),
+                                 (33333, 224)])
 def test_linear_bwd_fused_vs_fp64(R, C):
     """hotk_linear_bwd_fused (csrc/linbwd.hip): dx, dW and db of y = x @ W + b from one pass over dy, against fp64
     products; row counts that are not a multiple of the 256-row workgroup tile (and one below a single tile), padded
-    leading dimensions are exercised through the module path below."""
+    leading dimensions are exercised through the module path below.  Widths: fc_v (320), the node-level products of
+    Linear(2,2,'light') (864) and Linear(2,1,'light') (384) at the headline widths, one chunk, the widest supported, and a
+    chunk count (7) that splits into launches of unequal size."""
     _lib, ops, *_ = _product()
     torch.manual_seed(R + C)
     K = 32
