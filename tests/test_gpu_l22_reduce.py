@@ -138,6 +138,26 @@ def test_bwd_reduce_unsupported_shapes_are_refused():
     assert L.hotk_linear22_bwd_reduce_supported(64, C, 64) == 1
 
 
+def test_bwd_reduce_without_entry_rows_leaves_zeros():
+    """R = 0 (a batch of graphs without a single entry row): dyn and the one partial block leave as zeros, nothing is read"""
+    _lib, _, _ = _product()
+    L = _lib.lib()
+    B, Nmax = 2, 3
+    n = ctypes.c_int64()
+    assert L.hotk_linear22_bwd_reduce_partials(B, ctypes.byref(n)) == 0 and n.value == 2
+    dyn = torch.full((B * Nmax, 3 * C + 8), float('nan'), device=DEV)      # (padded leading dimension: the pad stays as it is)
+    part = torch.full((n.value, 64, C), float('nan'), device=DEV)
+    rc = L.hotk_linear22_bwd_reduce(None, C, None, 64, 64, C, None, None, None, None, None, None, B, Nmax, 0,
+                                    _lib.p(dyn), 3 * C + 8, _lib.p(part), _lib.stream_ptr())
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert float(dyn[:, :3 * C].abs().max()) == 0. and torch.isnan(dyn[:, 3 * C:]).all()
+    assert float(part.abs().max()) == 0.
+    # invalid: no partial buffer
+    assert L.hotk_linear22_bwd_reduce(None, C, None, 64, 64, C, None, None, None, None, None, None, B, Nmax, 0,
+                                      _lib.p(dyn), 3 * C + 8, None, _lib.stream_ptr()) != 0
+
+
 def test_light_basis_backward_uses_it_and_matches_the_three_kernel_form():
     """ops._l22_backward at the headline widths (D = 32 -> C = 288) on 60 BA(64,5) graphs: the one-pass reductions run
     (census), and every gradient equals the gather + pair-sum + library weight-gradient form to fp32 rounding"""
