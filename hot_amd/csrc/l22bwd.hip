@@ -413,7 +413,7 @@ extern "C" int hotk_linear22_bwd_reduce(const float* g, int64_t ldg, const float
     }
     return hipMemsetAsync(partial, 0, (size_t)rb_grid(B) * RB_K * RB_C * sizeof(float), st) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
   }
-  HOTK_CHECK_ARG(g && x2 && kind && rown && coln && g_ebeg && g_eend && n_nodes && dyn);
+  HOTK_CHECK_ARG(g && x2 && rown && coln && g_ebeg && g_eend && n_nodes && dyn);      // (kind is not read)
   HOTK_CHECK_ARG(hotk_aligned16(g) && (ldg & 3) == 0 && hotk_aligned16(x2) && (ld_x2 & 3) == 0);
   RbArgs a;
   a.G = g; a.ldg = ldg; a.X2 = x2; a.ldx = ld_x2; a.kind = kind; a.rown = rown; a.coln = coln;

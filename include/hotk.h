@@ -292,7 +292,8 @@ int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t l
  *   rows), summed by the caller in order (n = hotk_linear22_bwd_reduce_partials(B)).
  * All as bf16 matrix-core products on the exact three-way split of g (the sums against one-hot operands): fp32-exact
  * (2e-7), no atomics, bitwise reproducible.  Rows of graph b are [g_ebeg[b], g_eend[b]); node rows b * Nmax + local id;
- * n_nodes[b] nodes are real, the other node rows of dyn leave as zeros.  Every dyn row is written.  Shapes: K2 = 64,
+ * n_nodes[b] nodes are real, the other node rows of dyn leave as zeros.  Every dyn row is written.  Every row of a graph's range
+ * is taken as an entry, diagonal iff its row node equals its column node (`kind` is not read and may be NULL).  Shapes: K2 = 64,
  * C = 288, Nmax <= 64 (hotk_linear22_bwd_reduce_supported), others HOTK_EUNSUPPORTED.  g rows 16-byte aligned. */
 int hotk_linear22_bwd_reduce_supported(int64_t K2, int64_t C, int64_t Nmax);
 int hotk_linear22_bwd_reduce_partials(int64_t B, int64_t* n_partials);
