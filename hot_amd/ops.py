@@ -1582,17 +1582,23 @@ class AttnLayer22BF16(Function):
                                  torch.zeros((), dtype=torch.float32, device=dev))
         seg_sum_rows_bf16(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
         seg_sum_rows_bf16(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
-        db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
-        db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
         Wn = torch.cat([W2[0:D], W2[3 * D:4 * D], W2[4 * D:5 * D]], dim=1)
-        dxd = dyn @ Wn.t()
+        if linear_bwd_ok(Nn, D, 3 * C):
+            # node level (fp32 in this mode too): data gradient, weight gradient and both bias gradients from one pass
+            dxd, dWn, dbn = linear_bwd_fused(dyn, xd, Wn)
+            db_diag = dbn[0:C] if ctx.has_b[1] else None
+            db_off = dbn[C:2 * C] if ctx.has_b[0] else None
+        else:
+            db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
+            db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
+            dxd = dyn @ Wn.t()
+            dWn = wgrad(xd, dyn)
         dx2 = (g @ W2[D:3 * D].t().to(bf)).float()
         dx = torch.empty(R, D, dtype=torch.float32, device=dev)
         dxv32 = dxv.float()          # bound to a name: the block must stay out of the caching allocator until the launch is enqueued
         call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D,
              p(dxv32), D, p(dx), D, R, D)
         del dxv32
-        dWn = wgrad(xd, dyn)
         dW2 = torch.cat([dWn[:, 0:C], wgrad(x2b, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
         xshape, h1shape = ctx.shapes
         return (dx.view(xshape), dh1.view(h1shape), dW2, db_off, db_diag, dWv, dbv, dWo, dbo, None, None, None, None)
