@@ -50,6 +50,7 @@ _SIGNATURES = {
     'hotk_linear22_bwd_reduce_supported': [_L, _L, _L],
     'hotk_linear22_bwd_reduce_partials': [_L, ctypes.POINTER(_L)],
     'hotk_linear22_bwd_reduce': [_P, _L, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P],
+    'hotk_linear22_bwd_reduce_bf16': [_P, _L, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P],
     'hotk_seg_softmax_pool_fwd': [_P, _L, _P, _L, _P, _L, _P, _P, _P, _U, _P, _L, _P, _P, _P, _L, _I, _I, _I, _P],
     'hotk_seg_softmax_pool_bwd': [_P, _L, _P, _L, _P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _I, _P],
     'hotk_phi_fwd': [_P, _L, _P, _P, _U, _P, _L, _L, _I, _I, _I, _I, _P, _P],

@@ -76,8 +76,8 @@ struct Tile {          // wave-uniform
 };
 
 struct RbArgs {
-  const float* G; int64_t ldg;
-  const float* X2; int64_t ldx;
+  const void* G; int64_t ldg;       // float or (BF) bf16 rows; leading dimensions in elements
+  const void* X2; int64_t ldx;
   const uint8_t* kind; const int32_t* rown; const int32_t* coln;
   int B, Nmax;
   float* dyn; int64_t ld_dyn;
@@ -138,14 +138,16 @@ constexpr int RB_OFF_MASK = RB_OFF_META + 2 * 128;         // [2][row 64 | colum
 constexpr int RB_OFF_TAB = RB_OFF_MASK + 2 * 512;          // [256] u32x4: eight mask bits -> one-hot A fragment (bf16 1.0 / 0.0)
 constexpr int RB_LDS_BYTES = RB_OFF_TAB + 256 * 16;
 
-// NT: one-hot tiles of 32 nodes (Nmax <= 32 NT)
+// NT: one-hot tiles of 32 nodes (Nmax <= 32 NT).  BF: g and x2 are bf16 tensors (the bf16 storage mode): a value is its own
+// single plane -- one product per weight-gradient tile and per sum instead of six and three, no split; a wave's piece of a
+// tile row is 64 bytes, the DMA instruction covers 16 rows, and the load counts below are halved (G = 2, X = 1).
 //
 // Pipeline.  Tile t + 2 is requested (DMA) while tile t is multiplied: three stages of g per wave, two of the raw x2
 // fragments and node ids, two of the shared operands built from them (x2 planes, local ids).  Per iteration a wave issues
 // X loads for the shared operands it builds (two for an x2 fragment, one for the ids, none otherwise) and then four for
 // its g piece, always in that order and always all of them (past the last tile they re-read row 0), so the waits are
 // constants: g of tile t is older than X + 4 loads, the raw operands of tile t + 1 older than X + 8.
-template <int NT>
+template <int NT, bool BF>
 __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const int32_t* __restrict__ g_ebeg,
                                                                const int32_t* __restrict__ g_eend,
                                                                const int32_t* __restrict__ n_nodes) {
@@ -179,53 +181,84 @@ __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const i
     const int nlive = (int)(e1 - r0 < 32 ? (e1 > r0 ? e1 - r0 : 0) : 32);      // live rows of the tile
     if (frag >= 0) {
       const int kg = frag >> 1, mt = frag & 1;
-      const float* xb = a.X2 + rb * a.ldx + 32 * mt;
+      if constexpr (BF) {
+        const uint16_t* xb = reinterpret_cast<const uint16_t*>(a.X2) + rb * a.ldx + 32 * mt;
+        const int rl = 16 * kg + (lane >> 2);
+        const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldx + 8 * (lane & 3)) * 2);
+        rb_glds16s(xb, off, lds0 + RB_OFF_XRAW + (s2 * 4 + frag) * 2048);
+      } else {
+        const float* xb = reinterpret_cast<const float*>(a.X2) + rb * a.ldx + 32 * mt;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const int rl = 16 * kg + 8 * q + lr;
-        const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldx + lc) * 4);
-        rb_glds16s(xb, off, lds0 + RB_OFF_XRAW + ((s2 * 4 + frag) * 2 + q) * 1024);
+        for (int q = 0; q < 2; ++q) {
+          const int rl = 16 * kg + 8 * q + lr;
+          const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldx + lc) * 4);
+          rb_glds16s(xb, off, lds0 + RB_OFF_XRAW + ((s2 * 4 + frag) * 2 + q) * 1024);
+        }
       }
     } else if (meta_wave) {
       const int64_t rc = j < nlive ? rb + j : rb;
       rb_glds4((half ? a.coln : a.rown) + rc, lds0 + RB_OFF_MRAW + s2 * 256);
     }
-    const float* gb_ = a.G + rb * a.ldg + col0;
+    if constexpr (BF) {
+      const uint16_t* gb_ = reinterpret_cast<const uint16_t*>(a.G) + rb * a.ldg + col0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int rl = 8 * i + lr;
+      for (int i = 0; i < 2; ++i) {
+        const int rl = 16 * i + (lane >> 2);
+        const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldg + 8 * (lane & 3)) * 2);
+        rb_glds16s(gb_, off, lds0 + s3 * RB_G_STAGE + (wave * 4 + i) * 1024);
+      }
+    } else {
+      const float* gb_ = reinterpret_cast<const float*>(a.G) + rb * a.ldg + col0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rl = 8 * i + lr;
 #ifdef RB_PROBE_NOLOAD
-      const uint32_t off = (uint32_t)((rl * 0 + lc) * 4);
+        const uint32_t off = (uint32_t)((rl * 0 + lc) * 4);
 #else
-      const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldg + lc) * 4);
+        const uint32_t off = (uint32_t)(((rl < nlive ? rl : 0) * (int)a.ldg + lc) * 4);
 #endif
-      rb_glds16s(gb_, off, lds0 + s3 * RB_G_STAGE + (wave * 4 + i) * 1024);
+        rb_glds16s(gb_, off, lds0 + s3 * RB_G_STAGE + (wave * 4 + i) * 1024);
+      }
     }
   };
   // "the raw operands of the tile before the youngest two are in LDS" / "the g piece ..." for this wave's load count
   auto wait_raw = [&]() __attribute__((always_inline)) {
-    if (frag >= 0) rb_wait_vm<10>();
-    else if (meta_wave) rb_wait_vm<9>();
+    if (frag >= 0) rb_wait_vm<BF ? 5 : 10>();
+    else if (meta_wave) rb_wait_vm<BF ? 5 : 9>();
   };
   auto wait_g = [&]() __attribute__((always_inline)) {
-    if (frag >= 0) rb_wait_vm<6>();
-    else if (meta_wave) rb_wait_vm<5>();
-    else rb_wait_vm<4>();
+    if (frag >= 0) rb_wait_vm<BF ? 3 : 6>();
+    else if (meta_wave) rb_wait_vm<BF ? 3 : 5>();
+    else rb_wait_vm<BF ? 2 : 4>();
   };
   // shared operands of tile t from its raw slot s2 -> planes / ids buffer s2
   auto build_shared = [&](const Tile& t, int s2) __attribute__((always_inline)) {
     if (frag >= 0) {
       const int kg = frag >> 1;
-      const float* raw = reinterpret_cast<const float*>(lds + RB_OFF_XRAW) + (s2 * 4 + frag) * 512;
-      float v[8];
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float x = raw[(8 * half + e) * 32 + j];
-        v[e] = ((int64_t)t.r0 + 16 * kg + 8 * half + e < t.e1) ? x : 0.f;
-      }
-      const Planes p = rb_split8(v);
       u32x4* d = reinterpret_cast<u32x4*>(lds + RB_OFF_PLANES) + s2 * 12 * 64 + frag * 64 + lane;
-      d[0] = p.h; d[4 * 64] = p.m; d[8 * 64] = p.l;
+      if constexpr (BF) {
+        const uint16_t* raw = reinterpret_cast<const uint16_t*>(lds + RB_OFF_XRAW + (s2 * 4 + frag) * 2048);
+        uint32_t v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const uint32_t x = raw[(8 * half + e) * 32 + j];
+          v[e] = ((int64_t)t.r0 + 16 * kg + 8 * half + e < t.e1) ? x : 0u;
+        }
+        u32x4 h;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) h[q] = v[2 * q] | (v[2 * q + 1] << 16);
+        d[0] = h;
+      } else {
+        const float* raw = reinterpret_cast<const float*>(lds + RB_OFF_XRAW) + (s2 * 4 + frag) * 512;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float x = raw[(8 * half + e) * 32 + j];
+          v[e] = ((int64_t)t.r0 + 16 * kg + 8 * half + e < t.e1) ? x : 0.f;
+        }
+        const Planes p = rb_split8(v);
+        d[0] = p.h; d[4 * 64] = p.m; d[8 * 64] = p.l;
+      }
     }
     if (meta_wave) {
       // per node of the graph, the tile rows that are its off-diagonal row / column entries as a 32-bit mask: the one-hot
@@ -268,10 +301,20 @@ __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const i
   while (cur.b < a.B) {
     float* gt = reinterpret_cast<float*>(lds + s3 * RB_G_STAGE + wave * 4096);   // [32][32] this wave's piece of the tile
     wait_g();
+    const uint16_t* gtb = reinterpret_cast<const uint16_t*>(gt);                    // BF: [32][32] bf16
     if (cur.r0 + 32 > cur.e1) {           // the graph's last tile: rows past its end enter as zeros
+      if constexpr (BF) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if ((int64_t)cur.r0 + 8 * i + lr >= cur.e1) *reinterpret_cast<float4*>(gt + (8 * i + lr) * 32 + lc) = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < 2; ++i) {
+          const int rl = 16 * i + (lane >> 2);
+          if ((int64_t)cur.r0 + rl >= cur.e1)
+            *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(gt) + rl * 64 + 16 * (lane & 3)) = make_uint4(0u, 0u, 0u, 0u);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if ((int64_t)cur.r0 + 8 * i + lr >= cur.e1) *reinterpret_cast<float4*>(gt + (8 * i + lr) * 32 + lc) = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
     }
     rb_fence();
     {
@@ -295,7 +338,7 @@ __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const i
         const int r = __builtin_amdgcn_readfirstlane(__builtin_ctz(mask));
         mask &= mask - 1;
         const int node = __builtin_amdgcn_readlane(dn, r);
-        if (half == 0) a.dyn[(int64_t)node * a.ld_dyn + col0 + j] = gt[r * 32 + j];
+        if (half == 0) a.dyn[(int64_t)node * a.ld_dyn + col0 + j] = BF ? rb_u2f((uint32_t)gtb[r * 32 + j] << 16) : gt[r * 32 + j];
       }
     }
 #ifdef RB_PROBE_NOCOMP
@@ -303,16 +346,29 @@ __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const i
 #endif
 #pragma unroll 1
     for (int kg = 0; kg < 2; ++kg) {
-      float v[8];
+      Planes gb;
+      if constexpr (BF) {
+        uint32_t v[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = gt[(16 * kg + 8 * half + e) * 32 + j];
-      const Planes gb = rb_split8(v);
+        for (int e = 0; e < 8; ++e) v[e] = gtb[(16 * kg + 8 * half + e) * 32 + j];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gb.h[q] = v[2 * q] | (v[2 * q + 1] << 16);
+      } else {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = gt[(16 * kg + 8 * half + e) * 32 + j];
+        gb = rb_split8(v);
+      }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt) {
         const u32x4* s = xpl + (kg * 2 + mt) * 64 + lane;
-        Planes xa;
-        xa.h = s[0]; xa.m = s[4 * 64]; xa.l = s[8 * 64];
-        dw[mt] = rb_mfma6(xa, gb, dw[mt]);
+        if constexpr (BF) {
+          dw[mt] = rb_mfma(s[0], gb.h, dw[mt]);
+        } else {
+          Planes xa;
+          xa.h = s[0]; xa.m = s[4 * 64]; xa.l = s[8 * 64];
+          dw[mt] = rb_mfma6(xa, gb, dw[mt]);
+        }
       }
 #ifdef RB_PROBE_NOSUMS
       if (a.B < 0)
@@ -326,14 +382,18 @@ __global__ __launch_bounds__(64 * RB_NW) void k_l22_bwd_reduce(RbArgs a, const i
           const unsigned rb_ = (rmask[nt] >> (16 * kg)) & 0xffffu, cb_ = (cmask[nt] >> (16 * kg)) & 0xffffu;
           if (__builtin_amdgcn_ballot_w64(rb_ != 0u) != 0) {
             const u32x4 oh = tab[(rmask[nt] >> sh) & 0xffu];
-            rs[nt] = rb_mfma(oh, gb.l, rs[nt]);
-            rs[nt] = rb_mfma(oh, gb.m, rs[nt]);
+            if constexpr (!BF) {
+              rs[nt] = rb_mfma(oh, gb.l, rs[nt]);
+              rs[nt] = rb_mfma(oh, gb.m, rs[nt]);
+            }
             rs[nt] = rb_mfma(oh, gb.h, rs[nt]);
           }
           if (__builtin_amdgcn_ballot_w64(cb_ != 0u) != 0) {
             const u32x4 oc = tab[(cmask[nt] >> sh) & 0xffu];
-            cs[nt] = rb_mfma(oc, gb.l, cs[nt]);
-            cs[nt] = rb_mfma(oc, gb.m, cs[nt]);
+            if constexpr (!BF) {
+              cs[nt] = rb_mfma(oc, gb.l, cs[nt]);
+              cs[nt] = rb_mfma(oc, gb.m, cs[nt]);
+            }
             cs[nt] = rb_mfma(oc, gb.h, cs[nt]);
           }
         }
@@ -396,10 +456,11 @@ extern "C" int hotk_linear22_bwd_reduce_partials(int64_t B, int64_t* n_partials)
   return HOTK_OK;
 }
 
-extern "C" int hotk_linear22_bwd_reduce(const float* g, int64_t ldg, const float* x2, int64_t ld_x2, int64_t K2, int64_t C,
-                                        const uint8_t* kind, const int32_t* rown, const int32_t* coln, const int32_t* g_ebeg,
-                                        const int32_t* g_eend, const int32_t* n_nodes, int64_t B, int64_t Nmax, int64_t R,
-                                        float* dyn, int64_t ld_dyn, float* partial, void* stream) {
+namespace {
+template <bool BF>
+int rb_run(const void* g, int64_t ldg, const void* x2, int64_t ld_x2, int64_t K2, int64_t C, const int32_t* rown,
+           const int32_t* coln, const int32_t* g_ebeg, const int32_t* g_eend, const int32_t* n_nodes, int64_t B, int64_t Nmax,
+           int64_t R, float* dyn, int64_t ld_dyn, float* partial, void* stream) {
   HOTK_CHECK_ARG(B >= 0 && R >= 0 && ldg >= C && ld_x2 >= K2 && ld_dyn >= 3 * C);
   if (!hotk_linear22_bwd_reduce_supported(K2, C, Nmax)) return HOTK_EUNSUPPORTED;
   HOTK_CHECK_ARG(partial && B < ((int64_t)1 << 31) / (Nmax > 0 ? Nmax : 1) && R < ((int64_t)1 << 31));
@@ -414,21 +475,41 @@ extern "C" int hotk_linear22_bwd_reduce(const float* g, int64_t ldg, const float
     return hipMemsetAsync(partial, 0, (size_t)rb_grid(B) * RB_K * RB_C * sizeof(float), st) == hipSuccess ? HOTK_OK : HOTK_ELAUNCH;
   }
   HOTK_CHECK_ARG(g && x2 && rown && coln && g_ebeg && g_eend && n_nodes && dyn);      // (kind is not read)
-  HOTK_CHECK_ARG(hotk_aligned16(g) && (ldg & 3) == 0 && hotk_aligned16(x2) && (ld_x2 & 3) == 0);
+  // 16-byte row pieces: fp32 rows of 4 k elements, bf16 rows of 8 k
+  HOTK_CHECK_ARG(hotk_aligned16(g) && hotk_aligned16(x2) && ((ldg | ld_x2) & (BF ? 7 : 3)) == 0);
   RbArgs a;
-  a.G = g; a.ldg = ldg; a.X2 = x2; a.ldx = ld_x2; a.kind = kind; a.rown = rown; a.coln = coln;
+  a.G = g; a.ldg = ldg; a.X2 = x2; a.ldx = ld_x2; a.kind = nullptr; a.rown = rown; a.coln = coln;
   a.B = (int)B; a.Nmax = (int)Nmax;
   a.dyn = dyn; a.ld_dyn = ld_dyn; a.partial = partial;
   const size_t lds = RB_LDS_BYTES;
   const unsigned grid = rb_grid(B);
   static bool attr_set = false;   // (149 KB of dynamic LDS: above the 64 KB a kernel gets without asking)
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_l22_bwd_reduce<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_l22_bwd_reduce<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_l22_bwd_reduce<1, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_l22_bwd_reduce<2, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
   }
-  if (Nmax <= 32) hipLaunchKernelGGL((k_l22_bwd_reduce<1>), dim3(grid), dim3(64 * RB_NW), lds, st, a, g_ebeg, g_eend, n_nodes);
-  else hipLaunchKernelGGL((k_l22_bwd_reduce<2>), dim3(grid), dim3(64 * RB_NW), lds, st, a, g_ebeg, g_eend, n_nodes);
+  if (Nmax <= 32) hipLaunchKernelGGL((k_l22_bwd_reduce<1, BF>), dim3(grid), dim3(64 * RB_NW), lds, st, a, g_ebeg, g_eend, n_nodes);
+  else hipLaunchKernelGGL((k_l22_bwd_reduce<2, BF>), dim3(grid), dim3(64 * RB_NW), lds, st, a, g_ebeg, g_eend, n_nodes);
   return hotk_launch_status();
+}
+}  // namespace
+
+extern "C" int hotk_linear22_bwd_reduce(const float* g, int64_t ldg, const float* x2, int64_t ld_x2, int64_t K2, int64_t C,
+                                        const uint8_t* kind, const int32_t* rown, const int32_t* coln, const int32_t* g_ebeg,
+                                        const int32_t* g_eend, const int32_t* n_nodes, int64_t B, int64_t Nmax, int64_t R,
+                                        float* dyn, int64_t ld_dyn, float* partial, void* stream) {
+  (void)kind;
+  return rb_run<false>(g, ldg, x2, ld_x2, K2, C, rown, coln, g_ebeg, g_eend, n_nodes, B, Nmax, R, dyn, ld_dyn, partial, stream);
+}
+
+// g and x2 as bf16 tensors (leading dimensions in bf16 elements, multiples of 8); dyn and the partial blocks are fp32
+extern "C" int hotk_linear22_bwd_reduce_bf16(const void* g, int64_t ldg, const void* x2, int64_t ld_x2, int64_t K2, int64_t C,
+                                             const uint8_t* kind, const int32_t* rown, const int32_t* coln,
+                                             const int32_t* g_ebeg, const int32_t* g_eend, const int32_t* n_nodes, int64_t B,
+                                             int64_t Nmax, int64_t R, float* dyn, int64_t ld_dyn, float* partial,
+                                             void* stream) {
+  (void)kind;
+  return rb_run<true>(g, ldg, x2, ld_x2, K2, C, rown, coln, g_ebeg, g_eend, n_nodes, B, Nmax, R, dyn, ld_dyn, partial, stream);
 }

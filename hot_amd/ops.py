@@ -1577,11 +1577,23 @@ class AttnLayer22BF16(Function):
         if padded:
             g = torch.where((plan.kind != 0).unsqueeze(1), g, torch.zeros((), dtype=bf, device=dev))
         dyn = torch.empty(Nn, 3 * C, dtype=torch.float32, device=dev)
-        node_ok = (plan.nkind == 1).unsqueeze(1)
-        dyn[:, :C] = torch.where(node_ok, g.index_select(0, plan.diag_pos.clamp_min(0).long()).float(),
-                                 torch.zeros((), dtype=torch.float32, device=dev))
-        seg_sum_rows_bf16(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
-        seg_sum_rows_bf16(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
+        dW2e = None
+        if (_L22_REDUCE and R >= THIN_MIN_ROWS and type(plan).__name__ == 'Plan' and R < (1 << 31) and x2b.is_contiguous()
+                and lib().hotk_linear22_bwd_reduce_supported(2 * D, C, int(plan.Nmax)) == 1):
+            # diagonal gather, row / column sums and the entry-level weight gradient in one pass over dh2 (bf16 in, fp32 sums)
+            n = ctypes_long()
+            check(lib().hotk_linear22_bwd_reduce_partials(plan.B, byref(n)), 'hotk_linear22_bwd_reduce_partials')
+            part = torch.empty(n.value, 2 * D, C, dtype=torch.float32, device=dev)
+            call('hotk_linear22_bwd_reduce_bf16', 2 * plan.Ev * (C + 2 * D) + 12 * Nn * C, p(dh2), C, p(x2b), 2 * D, 2 * D, C,
+                 p(plan.kind), p(plan.rown), p(plan.coln), p(plan.g_ebeg), p(plan.g_eend), p(plan.n_nodes_dev), plan.B,
+                 plan.Nmax, R, p(dyn), 3 * C, p(part))
+            dW2e = part[0] if n.value == 1 else part.sum(0)
+        else:
+            node_ok = (plan.nkind == 1).unsqueeze(1)
+            dyn[:, :C] = torch.where(node_ok, g.index_select(0, plan.diag_pos.clamp_min(0).long()).float(),
+                                     torch.zeros((), dtype=torch.float32, device=dev))
+            seg_sum_rows_bf16(g, plan.row_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, C:2 * C])
+            seg_sum_rows_bf16(g, plan.col_seg(), plan.kind, KEEP_OFFDIAG, out=dyn[:, 2 * C:])
         Wn = torch.cat([W2[0:D], W2[3 * D:4 * D], W2[4 * D:5 * D]], dim=1)
         if linear_bwd_ok(Nn, D, 3 * C):
             # node level (fp32 in this mode too): data gradient, weight gradient and both bias gradients from one pass
@@ -1599,7 +1611,7 @@ class AttnLayer22BF16(Function):
         call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D,
              p(dxv32), D, p(dx), D, R, D)
         del dxv32
-        dW2 = torch.cat([dWn[:, 0:C], wgrad(x2b, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
+        dW2 = torch.cat([dWn[:, 0:C], dW2e if dW2e is not None else wgrad(x2b, g), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
         xshape, h1shape = ctx.shapes
         return (dx.view(xshape), dh1.view(h1shape), dW2, db_off, db_diag, dWv, dbv, dWo, dbo, None, None, None, None)
 

@@ -301,6 +301,13 @@ int hotk_linear22_bwd_reduce(const float* g, int64_t ldg, const float* x2, int64
                              const uint8_t* kind, const int32_t* rown, const int32_t* coln, const int32_t* g_ebeg,
                              const int32_t* g_eend, const int32_t* n_nodes, int64_t B, int64_t Nmax, int64_t R, float* dyn,
                              int64_t ld_dyn, float* partial, void* stream);
+/* the same with g and x2 as bf16 tensors (the bf16 storage mode; no counterpart in the reference): leading dimensions in
+ * bf16 elements, multiples of 8; a bf16 value is its own single plane, so every product is exact and dyn / partial (fp32)
+ * are fp32 sums of the stored bf16 values. */
+int hotk_linear22_bwd_reduce_bf16(const void* g, int64_t ldg, const void* x2, int64_t ld_x2, int64_t K2, int64_t C,
+                                  const uint8_t* kind, const int32_t* rown, const int32_t* coln, const int32_t* g_ebeg,
+                                  const int32_t* g_eend, const int32_t* n_nodes, int64_t B, int64_t Nmax, int64_t R,
+                                  float* dyn, int64_t ld_dyn, float* partial, void* stream);
 
 /* Wide dense projections as fp32-exact tiled GEMMs on the bf16 matrix pipe (csrc/gemm6.hip): every fp32 operand is split
  * exactly into three bf16 numbers and the six products of relative weight >= 2^-16 are summed in fp32 (1.8e-7 against

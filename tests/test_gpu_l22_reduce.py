@@ -129,6 +129,44 @@ def test_bwd_reduce_vs_fp64(case):
     assert torch.equal(dyn, dyn_b) and torch.equal(dW, dW_b)
 
 
+@pytest.mark.parametrize('case', ['ragged40', 'ragged17', 'ba300'])
+def test_bwd_reduce_bf16_inputs_vs_fp64(case):
+    """hotk_linear22_bwd_reduce_bf16 (the bf16 storage mode's form): dy and x2 as bf16 tensors, every product exact, fp32 sums
+    -- held to float64 sums of the stored bf16 values; NaN in the padding rows; two runs bit-identical"""
+    G = _batch(_ragged_graphs(int(case[6:]), 3), 4) if case.startswith('ragged') else _batch(_ba_graphs(300, 5), 6)
+    plan = G.plan
+    _lib, _, _ = _product()
+    L = _lib.lib()
+    g32, x32 = _inputs(plan, 21)
+    g, x2 = g32.to(torch.bfloat16), x32.to(torch.bfloat16)
+
+    def run():
+        n = ctypes.c_int64()
+        assert L.hotk_linear22_bwd_reduce_partials(plan.B, ctypes.byref(n)) == 0
+        dyn = torch.full((plan.Nn, 3 * C), float('nan'), device=DEV)
+        part = torch.full((n.value, 64, C), float('nan'), device=DEV)
+        p = _lib.p
+        rc = L.hotk_linear22_bwd_reduce_bf16(p(g), C, p(x2), 64, 64, C, None, p(plan.rown), p(plan.coln), p(plan.g_ebeg),
+                                             p(plan.g_eend), p(plan.n_nodes_dev), plan.B, plan.Nmax, plan.R, p(dyn), 3 * C,
+                                             p(part), _lib.stream_ptr())
+        assert rc == 0, rc
+        torch.cuda.synchronize()
+        return dyn, part.sum(0)
+    dyn, dW = run()
+    assert not torch.isnan(dyn).any() and not torch.isnan(dW).any()
+    g0 = torch.where(plan.kind.view(-1, 1) == 0, torch.zeros_like(g), g)
+    dyn64, dW64 = _reference64(plan, g0.float(), x2.float())
+    assert float((dyn.double() - dyn64).abs().max()) <= 2e-6 * float(dyn64.abs().max())
+    assert torch.equal(dyn[:, 0:C].double(), dyn64[:, 0:C])
+    assert float((dW.double() - dW64).abs().max()) <= 2e-6 * max(float(dW64.abs().max()), 1.)
+    dyn_b, dW_b = run()
+    assert torch.equal(dyn, dyn_b) and torch.equal(dW, dW_b)
+    # misaligned leading dimension (bf16 rows move in 16-byte pieces)
+    assert L.hotk_linear22_bwd_reduce_bf16(_lib.p(g), C + 4, _lib.p(x2), 64, 64, C, None, _lib.p(plan.rown), _lib.p(plan.coln),
+                                           _lib.p(plan.g_ebeg), _lib.p(plan.g_eend), _lib.p(plan.n_nodes_dev), plan.B, plan.Nmax,
+                                           plan.R, _lib.p(dyn), 3 * C, _lib.p(dW), _lib.stream_ptr()) != 0
+
+
 def test_bwd_reduce_unsupported_shapes_are_refused():
     _lib, _, _ = _product()
     L = _lib.lib()
