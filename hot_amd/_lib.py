@@ -47,6 +47,7 @@ _SIGNATURES = {
     'hotk_linear_bwd_supported': [_L, _L],
     'hotk_linear_bwd_partials': [_L, ctypes.POINTER(_L)],
     'hotk_linear_bwd_fused': [_P, _L, _P, _L, _P, _L, _L, _P, _L, _P, _L, _P],
+    'hotk_linear_bwd_fused_bf16': [_P, _L, _P, _L, _P, _L, _L, _P, _L, _P, _L, _P],
     'hotk_linear22_bwd_reduce_supported': [_L, _L, _L],
     'hotk_linear22_bwd_reduce_partials': [_L, ctypes.POINTER(_L)],
     'hotk_linear22_bwd_reduce': [_P, _L, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P, _L, _P, _P],

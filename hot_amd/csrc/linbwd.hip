@@ -14,6 +14,7 @@
 // once; dx, 1/10 of g, is re-read once).
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -34,6 +35,10 @@ __device__ __forceinline__ void lb_split3_pair(float x0, float x1, uint32_t& hi,
   lo = (lb_f2u(s0) >> 16) | (lb_f2u(s1) & 0xffff0000u);
 }
 struct Planes { u32x4 h, m, l; };
+// four bf16 values (as loaded: two packed pairs) -> fp32
+__device__ __forceinline__ float4 lb_widen(const uint2& u) {
+  return make_float4(lb_u2f(u.x << 16), lb_u2f(u.x & 0xffff0000u), lb_u2f(u.y << 16), lb_u2f(u.y & 0xffff0000u));
+}
 __device__ __forceinline__ Planes lb_split8(const float (&v)[8]) {
   Planes p;
   uint32_t h, m, l;
@@ -71,7 +76,9 @@ __device__ __forceinline__ void lb_fence() {
 // columns [c_lo, c_lo + 32 NCH) of g / W; Ctot = full width (row stride of W and of the partial blocks)
 // B6: both products as bf16 MFMAs (32x32x16) on split operands; W then sits in LDS as three bf16 planes
 // [plane][chunk][k step][k (32)][16 c] (a lane's A fragment = one ds_read_b128), behind the fp32 copy's place
-template <int NCH, bool WANT_DX, bool B6 = false>
+// GB: g and x are bf16 tensors (the bf16 storage mode; leading dimensions in bf16 elements): half the bytes in, widened to
+// fp32 when a piece is staged, the same products and fp32 results
+template <int NCH, bool WANT_DX, bool B6 = false, bool GB = false>
 __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __restrict__ G, int64_t ldg, const float* __restrict__ X,
                                                              int64_t ldx, const float* __restrict__ W, float* __restrict__ DX,
                                                              int64_t lddx, float* __restrict__ partial, int64_t R, int c_lo,
@@ -139,7 +146,10 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
     {
       float4 t[4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) t[i] = *reinterpret_cast<const float4*>(X + xoff[i]);
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (GB) t[i] = lb_widen(*reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(X) + xoff[i]));
+        else t[i] = *reinterpret_cast<const float4*>(X + xoff[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(xt + (8 * i + lr) * LB_OS + lc) = t[i];
       if (partial_tile) {
@@ -166,17 +176,23 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
     f32x16 dxa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dxa[r] = 0.f;
-    float4 nx[4];
+    typename std::conditional<GB, uint2, float4>::type nx[4];      // (GB: kept as loaded, widened at the staging write)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) nx[i] = *reinterpret_cast<const float4*>(G + goff[i]);
+    for (int i = 0; i < 4; ++i) {
+      if constexpr (GB) nx[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(G) + goff[i]);
+      else nx[i] = *reinterpret_cast<const float4*>(G + goff[i]);
+    }
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
       lb_fence();
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float* d = gt + (8 * i + lr) * LB_GS + lc;
-        *reinterpret_cast<float2*>(d) = make_float2(nx[i].x, nx[i].y);
-        *reinterpret_cast<float2*>(d + 2) = make_float2(nx[i].z, nx[i].w);
+        float4 w4;
+        if constexpr (GB) w4 = lb_widen(nx[i]);
+        else w4 = nx[i];
+        *reinterpret_cast<float2*>(d) = make_float2(w4.x, w4.y);
+        *reinterpret_cast<float2*>(d + 2) = make_float2(w4.z, w4.w);
       }
       if (partial_tile) {
 #pragma unroll
@@ -190,7 +206,10 @@ __global__ __launch_bounds__(64 * LB_WAVES) void k_linear_bwd(const float* __res
       lb_fence();
       if (ch + 1 < NCH) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) nx[i] = *reinterpret_cast<const float4*>(G + goff[i] + 32 * (ch + 1));
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (GB) nx[i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(G) + goff[i] + 32 * (ch + 1));
+          else nx[i] = *reinterpret_cast<const float4*>(G + goff[i] + 32 * (ch + 1));
+        }
       }
       // (the next chunk's loads stay HERE, in front of this chunk's products: at 250 registers the scheduler otherwise
       // sinks them to just before their use and the wave waits out the whole round trip)
@@ -306,25 +325,26 @@ bool lb_f32() {
   return v != 0;
 }
 
-template <int NCH, bool WANT_DX, bool B6>
+template <int NCH, bool WANT_DX, bool B6, bool GB = false>
 int lb_launch_t(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
               float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
   constexpr int C = 32 * NCH;
   const size_t lds = ((size_t)(B6 ? (3 * LB_K * C) / 2 : LB_K * (C + 2)) + (size_t)LB_WAVES * (32 * LB_GS + 32 * LB_OS)) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_linear_bwd<NCH, WANT_DX, B6>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)k_linear_bwd<NCH, WANT_DX, B6, GB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_linear_bwd<NCH, WANT_DX, B6>), dim3(lb_grid(R)), dim3(64 * LB_WAVES), lds, st, G, ldg, X, ldx, W, DX, lddx, partial, R,
+  hipLaunchKernelGGL((k_linear_bwd<NCH, WANT_DX, B6, GB>), dim3(lb_grid(R)), dim3(64 * LB_WAVES), lds, st, G, ldg, X, ldx, W, DX, lddx, partial, R,
                      c_lo, Ctot, add_dx);
   return hotk_launch_status();
 }
 
-template <int NCH, bool WANT_DX>
+template <int NCH, bool WANT_DX, bool GB = false>
 int lb_launch(const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
               float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
+  if constexpr (GB) return lb_launch_t<NCH, WANT_DX, false, true>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
   return lb_f32() ? lb_launch_t<NCH, WANT_DX, false>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st)
                   : lb_launch_t<NCH, WANT_DX, true>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
 }
@@ -333,15 +353,15 @@ int lb_launch(const float* G, int64_t ldg, const float* X, int64_t ldx, const fl
 
 namespace {
 // one launch over the chunks [c_lo, c_lo + 32 nch) of g / W
-template <bool WANT_DX>
+template <bool WANT_DX, bool GB>
 int lb_launch_n(int nch, const float* G, int64_t ldg, const float* X, int64_t ldx, const float* W, float* DX, int64_t lddx,
                 float* partial, int64_t R, int c_lo, int Ctot, int add_dx, hipStream_t st) {
   switch (nch) {
-    case 1: return lb_launch<1, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
-    case 2: return lb_launch<2, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
-    case 3: return lb_launch<3, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
-    case 4: return lb_launch<4, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
-    default: return lb_launch<5, WANT_DX>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 1: return lb_launch<1, WANT_DX, GB>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 2: return lb_launch<2, WANT_DX, GB>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 3: return lb_launch<3, WANT_DX, GB>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    case 4: return lb_launch<4, WANT_DX, GB>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
+    default: return lb_launch<5, WANT_DX, GB>(G, ldg, X, ldx, W, DX, lddx, partial, R, c_lo, Ctot, add_dx, st);
   }
 }
 constexpr int LB_MAX_C = 1024;
@@ -359,12 +379,15 @@ extern "C" int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials) {
   return HOTK_OK;
 }
 
-extern "C" int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K,
-                                     int64_t C, float* dx, int64_t lddx, float* partial, int64_t R, void* stream) {
+namespace {
+template <bool GB>
+int lb_run(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K, int64_t C, float* dx,
+           int64_t lddx, float* partial, int64_t R, void* stream) {
   HOTK_CHECK_ARG(R >= 0 && ldg >= C && ldx >= K && (!dx || lddx >= K));
   if (!hotk_linear_bwd_supported(K, C)) return HOTK_EUNSUPPORTED;
   HOTK_CHECK_ARG(g && x && partial && (!dx || W));
-  HOTK_CHECK_ARG(hotk_aligned16(g) && hotk_aligned16(x) && (!dx || hotk_aligned16(dx)) && ((ldg | ldx) & 3) == 0 &&
+  // row pieces of four values: 16 bytes of fp32, 8 bytes of bf16
+  HOTK_CHECK_ARG((((uintptr_t)g | (uintptr_t)x) & (GB ? 7u : 15u)) == 0 && (!dx || hotk_aligned16(dx)) && ((ldg | ldx) & 3) == 0 &&
                  (!dx || (lddx & 3) == 0));
   if (R == 0) {
     // the caller sums lb_grid(0) = 1 partial block: give it zeros
@@ -377,10 +400,23 @@ extern "C" int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x
   int c_lo = 0;
   for (int l = 0; l < launches; ++l) {
     const int nch = chunks / launches + (l < chunks % launches ? 1 : 0);
-    const int rc = dx ? lb_launch_n<true>(nch, g, ldg, x, ldx, W, dx, lddx, partial, R, c_lo, (int)C, l > 0 ? 1 : 0, st)
-                      : lb_launch_n<false>(nch, g, ldg, x, ldx, W, dx, lddx, partial, R, c_lo, (int)C, 0, st);
+    const int rc = dx ? lb_launch_n<true, GB>(nch, g, ldg, x, ldx, W, dx, lddx, partial, R, c_lo, (int)C, l > 0 ? 1 : 0, st)
+                      : lb_launch_n<false, GB>(nch, g, ldg, x, ldx, W, dx, lddx, partial, R, c_lo, (int)C, 0, st);
     if (rc) return rc;
     c_lo += 32 * nch;
   }
   return HOTK_OK;
+}
+}  // namespace
+
+extern "C" int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K,
+                                     int64_t C, float* dx, int64_t lddx, float* partial, int64_t R, void* stream) {
+  return lb_run<false>(g, ldg, x, ldx, W, K, C, dx, lddx, partial, R, stream);
+}
+
+// g and x as bf16 tensors (leading dimensions in bf16 elements, multiples of 4); W, dx and the partial blocks are fp32
+extern "C" int hotk_linear_bwd_fused_bf16(const void* g, int64_t ldg, const void* x, int64_t ldx, const float* W, int64_t K,
+                                          int64_t C, float* dx, int64_t lddx, float* partial, int64_t R, void* stream) {
+  return lb_run<true>(reinterpret_cast<const float*>(g), ldg, reinterpret_cast<const float*>(x), ldx, W, K, C, dx, lddx, partial,
+                      R, stream);
 }

@@ -246,10 +246,16 @@ def linear_bwd_fused(g, x, w):
     K = x.size(1)
     n = ctypes_long()
     check(lib().hotk_linear_bwd_partials(R, byref(n)), 'hotk_linear_bwd_partials')
-    part = torch.empty(n.value, K + 2, C, dtype=g.dtype, device=g.device)
-    dx = torch.empty(R, K, dtype=g.dtype, device=g.device) if w is not None else None
-    call('hotk_linear_bwd_fused', 4 * R * (C + 2 * K), p(g), C, p(x), K, p(None if w is None else w.contiguous()), K, C,
-         p(dx), K, p(part), R)
+    part = torch.empty(n.value, K + 2, C, dtype=torch.float32, device=g.device)
+    dx = torch.empty(R, K, dtype=torch.float32, device=g.device) if w is not None else None
+    if g.dtype == torch.bfloat16:
+        # bf16 storage mode: g and x as stored (hotk_linear_bwd_fused_bf16), fp32 weight and results
+        assert x.dtype == torch.bfloat16 and g.is_contiguous() and x.is_contiguous()
+        call('hotk_linear_bwd_fused_bf16', 2 * R * (C + K) + 4 * R * K, p(g), C, p(x), K, p(None if w is None else w.float().contiguous()),
+             K, C, p(dx), K, p(part), R)
+    else:
+        call('hotk_linear_bwd_fused', 4 * R * (C + 2 * K), p(g), C, p(x), K, p(None if w is None else w.contiguous()), K, C,
+             p(dx), K, p(part), R)
     tot = part.sum(0)
     return dx, tot[:K], tot[K] + tot[K + 1]
 
@@ -1569,9 +1575,14 @@ class AttnLayer22BF16(Function):
         call('hotk_attn22_backward', plan.Ev * (2 * (8 * 32 * 2 + 10 * 32 * 3) + 25) + 4 * Nn * 384 * 2, byref(a), p(ws), nws)
         seg_sum_rows_bf16(ck, plan.row_seg(), None, KEEP_VALID, out=dh1[:, 128:320])
         # fc_v backward (bf16 GEMMs, fp32 sums)
-        dxv = dv @ Wv.to(bf)                                             # [R, D]
-        dWv = wgrad(dv, xb)                                              # [320, D]
-        dbv = dv.sum(0, dtype=torch.float32)
+        if linear_bwd_ok(R, D, 320):
+            # dx, dW and db from ONE pass over dv (bf16 in, fp32 out) instead of two library GEMMs and a column sum
+            dxv32, dWv_t, dbv = linear_bwd_fused(dv, xb, Wv.t())
+            dWv = dWv_t.t()
+        else:
+            dxv32 = (dv @ Wv.to(bf)).float()                                 # [R, D]
+            dWv = wgrad(dv, xb)                                              # [320, D]
+            dbv = dv.sum(0, dtype=torch.float32)
         # fc_2 backward: g = dh2; padding rows of g were never written
         g = dh2
         if padded:
@@ -1607,7 +1618,6 @@ class AttnLayer22BF16(Function):
             dWn = wgrad(xd, dyn)
         dx2 = (g @ W2[D:3 * D].t().to(bf)).float()
         dx = torch.empty(R, D, dtype=torch.float32, device=dev)
-        dxv32 = dxv.float()          # bound to a name: the block must stay out of the caching allocator until the launch is enqueued
         call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D,
              p(dxv32), D, p(dx), D, R, D)
         del dxv32

@@ -283,6 +283,10 @@ int hotk_linear_bwd_supported(int64_t K, int64_t C);
 int hotk_linear_bwd_partials(int64_t R, int64_t* n_partials);
 int hotk_linear_bwd_fused(const float* g, int64_t ldg, const float* x, int64_t ldx, const float* W, int64_t K, int64_t C,
                           float* dx, int64_t lddx, float* partial, int64_t R, void* stream);
+/* the same with g and x as bf16 tensors (the bf16 storage mode; no counterpart in the reference): leading dimensions in bf16
+ * elements (multiples of 4, rows 8-byte aligned); values are widened to fp32 on the way in, W / dx / partial are fp32. */
+int hotk_linear_bwd_fused_bf16(const void* g, int64_t ldg, const void* x, int64_t ldx, const float* W, int64_t K, int64_t C,
+                               float* dx, int64_t lddx, float* partial, int64_t R, void* stream);
 
 /* Entry-level reductions of the backward pass of the factored Linear(2, 2, 'light') (models/sparse/linear.py:143-161,
  * 293-306 under autograd: the scatter_add_ of the diagonal / row / column gathers and the weight gradient of the entry

@@ -369,6 +369,25 @@ def test_linear_bwd_fused_vs_fp64(R, C):
         assert rel_err(b.grad.cpu(), gd.sum(0).cpu()) < TOL
 
 
+@pytest.mark.parametrize('R,C', [(40001, 320), (300, 96)])
+def test_linear_bwd_fused_bf16_inputs_vs_fp64(R, C):
+    """hotk_linear_bwd_fused_bf16 (the bf16 storage mode's fc_v backward): dy and x as bf16 tensors, widened on the way in,
+    fp32 weight and results -- against float64 products of the stored bf16 values, with and without the data gradient"""
+    _lib, ops, *_ = _product()
+    torch.manual_seed(R + C)
+    g = torch.randn(R, C, device=DEV).to(torch.bfloat16)
+    x = torch.randn(R, 32, device=DEV).to(torch.bfloat16)
+    w = torch.randn(32, C, device=DEV)
+    dx, dw, db = ops.linear_bwd_fused(g, x, w)
+    assert dx.dtype == dw.dtype == db.dtype == torch.float32
+    gd, xd, wd = g.double(), x.double(), w.double()
+    assert rel_err(dx.cpu(), (gd @ wd.t()).cpu()) < TOL
+    assert rel_err(dw.cpu(), (xd.t() @ gd).cpu()) < TOL
+    assert rel_err(db.cpu(), gd.sum(0).cpu()) < TOL
+    none, dw2, db2 = ops.linear_bwd_fused(g, x, None)
+    assert none is None and torch.equal(dw2, dw) and torch.equal(db2, db)
+
+
 def test_linear22_entry_gemm_matches_assemble_path():
     """entry GEMM of the factored Linear(2,2,'light') with the fused assembly epilogue (hotk_linear22_entry_fwd) against
     the library GEMM + hotk_assemble22 path, on ragged graphs (padding rows, one-directional edges), incl. gradients"""
