@@ -43,6 +43,7 @@ _SIGNATURES = {
     'hotk_thin_gemm_supported': [_L, _L],
     'hotk_thin_gemm_bias': [_P, _L, _P, _L, _L, _P, _P, _L, _P, _L, _L, _P],
     'hotk_thin_gemm_bias_bf16': [_P, _L, _P, _L, _L, _P, _P, _L, _L, _P],
+    'hotk_thin_gemm_bias_bf16in': [_P, _L, _P, _L, _L, _P, _P, _L, _P, _L, _L, _P],
     'hotk_linear22_entry_fwd': [_P, _L, _P, _L, _L, _P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_linear_bwd_supported': [_L, _L],
     'hotk_linear_bwd_partials': [_L, ctypes.POINTER(_L)],

@@ -116,7 +116,9 @@ __device__ __forceinline__ void gemm_wave_fence() {
 // matrix): the epilogue then has no branch around its stores, the compiler can COUNT them, and the wait for the
 // prefetched addends of the next tile becomes vmcnt(4) instead of vmcnt(0) -- a wait for every store of the tile to
 // complete (loads and stores share the in-order counter).
-template <int KH, int TG, int MODE, int NW, bool B6 = false, bool RES = false, bool OB = false>
+// IB (wide-input stream form only): A is a bf16 tensor (lda in bf16 elements) -- a value is its own plane: the lane's eight k
+// values of a step are ONE 16-byte load and the B fragment as loaded, three products per step and column tile, no split
+template <int KH, int TG, int MODE, int NW, bool B6 = false, bool RES = false, bool OB = false, bool IB = false>
 __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                           float* __restrict__ Y, int64_t ldy, int64_t R, int C, Epi ep) {
   constexpr int WAVES = NW;
@@ -128,6 +130,7 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
   // instead of being held for the whole tile, and the TG column tiles of a group share each split
   constexpr bool STREAM = B6 && KS > 4;
   static_assert(!B6 || (K % 16 == 0 && (STREAM || TG == 1)), "B6: whole 16-k steps; narrow inputs: one column tile per loop");
+  static_assert(!IB || STREAM, "bf16 rows: the wide-input stream form only");
   const int w_floats = B6 ? (3 * K * C) / 2 : K * C; // LDS floats taken by the weight
   if (B6) {
     uint16_t* wb = reinterpret_cast<uint16_t*>(w_lds);
@@ -248,7 +251,77 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
       for (int t = 0; t < TG; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-      if constexpr (STREAM) {
+      if constexpr (STREAM && IB) {
+        const uint16_t* ap = reinterpret_cast<const uint16_t*>(A) + row * lda + 8 * half;
+        auto fetch = [&](int ks, u32x4& x) __attribute__((always_inline)) {
+          const int kc = ks < KS ? ks : KS - 1;
+          x = *reinterpret_cast<const u32x4*>(ap + 16 * kc);
+        };
+        // the weight fragments of a step are read from LDS one step ahead as well (two named sets): read right before their
+        // products, their latency stood in front of every step (3.87 ms for the two bf16 products of a layer step against 3.2)
+        struct WF { u32x4 h[TG], m[TG], l[TG]; };
+        auto wload = [&](int ks, WF& w) __attribute__((always_inline)) {
+          const int kc = ks < KS ? ks : KS - 1;
+#pragma unroll
+          for (int t = 0; t < TG; ++t) {
+            w.h[t] = wq[((0 * KS + kc) * C + n0 + 32 * t) * 2];
+            w.m[t] = wq[((1 * KS + kc) * C + n0 + 32 * t) * 2];
+            w.l[t] = wq[((2 * KS + kc) * C + n0 + 32 * t) * 2];
+          }
+        };
+        auto products = [&](const WF& w, const u32x4& bh) __attribute__((always_inline)) {
+#pragma unroll
+          for (int t = 0; t < TG; ++t) {
+            acc[t] = mfma_bf16(w.l[t], bh, acc[t]);
+            acc[t] = mfma_bf16(w.m[t], bh, acc[t]);
+            acc[t] = mfma_bf16(w.h[t], bh, acc[t]);
+          }
+        };
+        // rows three steps ahead in four named register sets (16 bytes per lane and step)
+        static_assert(KS % 2 == 0 && KS >= 6, "pairs of k steps, at least one round of four");
+        if constexpr (!RES) {
+          // without a residual the whole k loop is unrolled (every address an immediate, the fragment reads scheduled across
+          // steps: 3.2 ms for the two bf16 products of a layer step against 3.7 for the loop below); with one, the epilogue's
+          // addends push that form over 256 registers
+          u32x4 ring[4];
+#pragma unroll
+          for (int d = 0; d < 3; ++d) fetch(d, ring[d]);
+#pragma unroll
+          for (int k2 = 0; k2 < KS; ++k2) {
+            fetch(k2 + 3, ring[(k2 + 3) % 4]);
+            WF w;
+            wload(k2, w);
+            __builtin_amdgcn_sched_barrier(0);
+            products(w, ring[k2 % 4]);
+          }
+        } else {
+        u32x4 r0, r1, r2, r3;
+        WF wa, wb;
+        fetch(0, r0); fetch(1, r1); fetch(2, r2);
+        wload(0, wa);
+        int ks = 0;
+#pragma unroll 1
+        for (; ks + 4 <= KS; ks += 4) {
+          fetch(ks + 3, r3); wload(ks + 1, wb);
+          __builtin_amdgcn_sched_barrier(0);
+          products(wa, r0);
+          fetch(ks + 4, r0); wload(ks + 2, wa);              // (past the end: the last piece again)
+          __builtin_amdgcn_sched_barrier(0);
+          products(wb, r1);
+          fetch(ks + 5, r1); wload(ks + 3, wb);
+          __builtin_amdgcn_sched_barrier(0);
+          products(wa, r2);
+          fetch(ks + 6, r2); wload(ks + 4, wa);
+          __builtin_amdgcn_sched_barrier(0);
+          products(wb, r3);
+        }
+        if constexpr (KS % 4 == 2) {      // r0, r1 hold the last two steps, wa the first one's weight fragments
+          wload(KS - 1, wb);
+          products(wa, r0);
+          products(wb, r1);
+        }
+        }
+      } else if constexpr (STREAM) {
         // One step ahead.  At K = 320 -> 32 with a residual the kernel moves 15.4 GB in 3.1-3.4 ms (4.5-5 TB/s): it is near the
         // streaming ceiling, and every deeper or wider form of the row stream measured slower -- 8-k pieces 2 / 4 / 6
         // steps ahead 5.5 / 5.1 / 3.3 ms, a lane's 64 contiguous bytes of each line two lines ahead (k order permuted
@@ -381,14 +454,14 @@ __global__ __launch_bounds__(64 * NW) void k_thin_gemm(const float* __restrict__
   }
 }
 
-template <int KH, int TG, int MODE, int NW, bool B6, bool RES, bool OB>
+template <int KH, int TG, int MODE, int NW, bool B6, bool RES, bool OB, bool IB = false>
 int launch_v(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy, int64_t R, int C, const Epi& ep,
              hipStream_t st) {
   constexpr int WAVES = NW;
   const size_t lds = ((size_t)(B6 ? 3 : 2) * KH * C + (size_t)WAVES * 32 * OS + 2 * (size_t)C) * sizeof(float);
   static bool attr_set = false;   // raising the dynamic-LDS limit of a kernel is a per-process property of the function
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW, B6, RES, OB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)k_thin_gemm<KH, TG, MODE, NW, B6, RES, OB, IB>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
         hipSuccess)
       return HOTK_ELAUNCH;
     attr_set = true;
@@ -397,7 +470,7 @@ int launch_v(const float* A, int64_t lda, const float* W, float* Y, int64_t ldy,
   // persistent workgroups: two per CU where the weight and the result images allow it
   const int per_cu = lds <= 80 * 1024 ? 2 : 1;
   const unsigned grid = (unsigned)(n_tiles < 256 * per_cu ? n_tiles : 256 * per_cu);
-  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW, B6, RES, OB>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
+  hipLaunchKernelGGL((k_thin_gemm<KH, TG, MODE, NW, B6, RES, OB, IB>), dim3(grid), dim3(64 * WAVES), lds, st, A, lda, W, Y, ldy, R, C, ep);
   return hotk_launch_status();
 }
 
@@ -496,6 +569,29 @@ extern "C" int hotk_thin_gemm_bias_bf16(const float* A, int64_t lda, const float
   ep.bias = bias;
   ep.out_bf16 = 1;
   return dispatch<0>(A, lda, W, K, C, (float*)Y, ldy, R, ep, (hipStream_t)stream);
+}
+
+// Y[R, C] (fp32) = A[R, K] (bf16 rows) . W[K, C] (fp32) (+ bias) (+ res, fp32): the wide-input products of the bf16 storage mode
+// (fc_o: K = 320 -> 32; the entry blocks' data gradient: K = 288 -> 64); every product of a bf16 value with a three-way split
+// weight is exact, fp32 accumulation
+extern "C" int hotk_thin_gemm_bias_bf16in(const void* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
+                                          const float* res, int64_t ld_res, float* Y, int64_t ldy, int64_t R, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && K > 0 && C > 0 && lda >= K && ldy >= C && (!res || ld_res >= C));
+  const bool fits = ((size_t)3 * (K / 2) * C + (size_t)8 * 32 * OS + 2 * (size_t)C) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
+  if (!((K == 288 && C % 64 == 0) || (K == 320 && C % 32 == 0)) || !fits) return HOTK_EUNSUPPORTED;
+  if (R == 0) return HOTK_OK;
+  HOTK_CHECK_ARG(A && W && Y && hotk_aligned16(A) && hotk_aligned16(W) && (lda & 7) == 0);
+  HOTK_CHECK_ARG(hotk_aligned16(Y) && (ldy & 3) == 0 && (!bias || hotk_aligned16(bias)) &&
+                 (!res || (hotk_aligned16(res) && (ld_res & 3) == 0)));
+  Epi ep{};
+  ep.bias = bias; ep.res = res; ep.ld_res = ld_res;
+  const float* a = reinterpret_cast<const float*>(A);
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 288)
+    return res ? launch_v<144, 2, 0, 8, true, true, false, true>(a, lda, W, Y, ldy, R, (int)C, ep, st)
+               : launch_v<144, 2, 0, 8, true, false, false, true>(a, lda, W, Y, ldy, R, (int)C, ep, st);
+  return res ? launch_v<160, 1, 0, 8, true, true, false, true>(a, lda, W, Y, ldy, R, (int)C, ep, st)
+             : launch_v<160, 1, 0, 8, true, false, false, true>(a, lda, W, Y, ldy, R, (int)C, ep, st);
 }
 
 namespace {

@@ -286,6 +286,23 @@ def thin_gemm(A, W, bias=None, res=None):
     return Y
 
 
+def thin_in_ok(R, K, C):
+    """hotk_thin_gemm_bias_bf16in covers this product (bf16 rows in, fp32 out: the wide-input stream forms)"""
+    return R >= THIN_MIN_ROWS and ((K == 288 and C % 64 == 0) or (K == 320 and C % 32 == 0)) and thin_ok(R, K, C)
+
+
+def thin_gemm_bf16in(A, W, bias=None):
+    """Y[R, C] (fp32) = A[R, K] (bf16) @ W[K, C] (fp32) (+ bias), exact products, fp32 accumulation; call thin_in_ok first"""
+    assert A.dtype == torch.bfloat16 and A.dim() == 2 and A.is_contiguous()
+    R, K = A.shape
+    W = W.float().contiguous()
+    C = W.size(1)
+    assert W.size(0) == K
+    Y = torch.empty(R, C, dtype=torch.float32, device=A.device)
+    call('hotk_thin_gemm_bias_bf16in', R * (2 * K + 4 * C), p(A), K, p(W), K, C, p(bias), p(None), 0, p(Y), C, R)
+    return Y
+
+
 def thin_gemm_bf16(A, W, bias=None):
     """Y[R, C] (bf16) = A[R, 32] @ W[32, C] (+ bias), fp32 operands and accumulation, rounded at the store
     (hotk_thin_gemm_bias_bf16); call thin_wide_ok first"""
@@ -1530,8 +1547,11 @@ class AttnLayer22BF16(Function):
         mu, keep = AttnCore22._drop_masks(plan, dev, drop_p, mu_p)
         AttnCore22._drop_apply(att, plan, mu, keep, drop_p)
         # fc_o + bias + skip path
-        y = (att @ Wo.t().to(bf)).float()
-        y += bo
+        if thin_in_ok(R, 320, D):
+            y = thin_gemm_bf16in(att, Wo.t(), bo)       # bf16 rows in, fp32 out, bias in the epilogue
+        else:
+            y = (att @ Wo.t().to(bf)).float()
+            y += bo
         y += h2[:, 256:]
         if padded:
             y = mask_rows(y, plan.kind, KEEP_VALID, 0.0)
@@ -1616,7 +1636,7 @@ class AttnLayer22BF16(Function):
             db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
             dxd = dyn @ Wn.t()
             dWn = wgrad(xd, dyn)
-        dx2 = (g @ W2[D:3 * D].t().to(bf)).float()
+        dx2 = thin_gemm_bf16in(g, W2[D:3 * D].t()) if thin_in_ok(R, C, 2 * D) else (g @ W2[D:3 * D].t().to(bf)).float()
         dx = torch.empty(R, D, dtype=torch.float32, device=dev)
         call('hotk_basis22_pair_bwd', 4 * R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown), p(dxd), D,
              p(dxv32), D, p(dx), D, R, D)

@@ -179,6 +179,11 @@ int hotk_thin_gemm_bias(const float* A, int64_t lda, const float* W, int64_t K, 
  * and d att = d y . W_o of the bf16 storage mode (models/sparse/kernelattn.py:51,65-72 at the north_star's 2e-2). */
 int hotk_thin_gemm_bias_bf16(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
                              void* Y, int64_t ldy, int64_t R, void* stream);
+/* Y[R, C] (fp32) = A[R, K] (bf16 rows, lda in bf16 elements, a multiple of 8) @ W[K, C] (fp32) (+ bias) (+ res, fp32): the wide-input
+ * products of the bf16 storage mode (fc_o: K = 320; the entry blocks' data gradient of Linear(2,2,'light'): K = 288 -> 64; no
+ * counterpart in the reference).  A bf16 value is its own plane: three exact products per step against the split weight. */
+int hotk_thin_gemm_bias_bf16in(const void* A, int64_t lda, const float* W, int64_t K, int64_t C, const float* bias,
+                               const float* res, int64_t ld_res, float* Y, int64_t ldy, int64_t R, void* stream);
 int hotk_linear22_entry_fwd(const float* x2, int64_t ld_x2, const float* W, int64_t K, int64_t C, const float* yn,
                             int64_t ld_yn, const uint8_t* kind, const int32_t* rown, const int32_t* coln,
                             const float* b_off, const float* b_diag, float* Y, int64_t ldy, int64_t R, int64_t Nn, void* stream);

@@ -369,6 +369,23 @@ def test_linear_bwd_fused_vs_fp64(R, C):
         assert rel_err(b.grad.cpu(), gd.sum(0).cpu()) < TOL
 
 
+@pytest.mark.parametrize('K,C', [(320, 32), (288, 64)])
+def test_thin_gemm_bf16_rows_in_vs_fp64(K, C):
+    """hotk_thin_gemm_bias_bf16in: bf16 rows in, fp32 weight, bias and result -- against float64 products of the stored bf16
+    values; a row count that is not a multiple of the 256-row workgroup tile"""
+    _lib, ops, *_ = _product()
+    torch.manual_seed(K + C)
+    R = 70003
+    assert ops.thin_in_ok(R, K, C)
+    A = torch.randn(R, K, device=DEV).to(torch.bfloat16)
+    W = torch.randn(K, C, device=DEV) / K ** 0.5
+    b = torch.randn(C, device=DEV)
+    y = ops.thin_gemm_bf16in(A, W, b)
+    assert y.dtype == torch.float32
+    assert rel_err(y.cpu(), (A.double() @ W.double() + b.double()).cpu()) < TOL
+    assert rel_err(ops.thin_gemm_bf16in(A, W).cpu(), (A.double() @ W.double()).cpu()) < TOL
+
+
 @pytest.mark.parametrize('R,C', [(40001, 320), (300, 96)])
 def test_linear_bwd_fused_bf16_inputs_vs_fp64(R, C):
     """hotk_linear_bwd_fused_bf16 (the bf16 storage mode's fc_v backward): dy and x as bf16 tensors, widened on the way in,
