@@ -39,7 +39,7 @@ BYTES_PER_NODE = 2 * 4 * 12 * DQK + 3 * 2 * 2 * 4 * 2 * HEADS * 16 * (DV // HEAD
 # profiles/r02_pmc_traffic_attn22.txt, collected with scratch/pmc_traffic.sh at the benchmarked size (10 M entries; the
 # round-1 pass at 2 M entries gave 4903 / 8584, the mid-round-2 pass 4886 / 8592; re-collected at the end of round 2: the
 # ticketed kernels hold more waves resident and re-read more of a node's rows past L2 -- they fetch more and run faster)
-PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 5259, 'hotk_attn22_backward': 10054}
+PMC_TRAFFIC_BYTES_PER_ENTRY = {'hotk_attn22_forward': 5261, 'hotk_attn22_backward': 10058}
 PMC_TRAFFIC_SOURCE = 'profiles/r03_pmc_traffic_attn22.txt'
 
 
