@@ -291,15 +291,20 @@ def thin_in_ok(R, K, C):
     return R >= THIN_MIN_ROWS and ((K == 288 and C % 64 == 0) or (K == 320 and C % 32 == 0)) and thin_ok(R, K, C)
 
 
-def thin_gemm_bf16in(A, W, bias=None):
-    """Y[R, C] (fp32) = A[R, K] (bf16) @ W[K, C] (fp32) (+ bias), exact products, fp32 accumulation; call thin_in_ok first"""
+def thin_gemm_bf16in(A, W, bias=None, res=None):
+    """Y[R, C] (fp32) = A[R, K] (bf16) @ W[K, C] (fp32) (+ bias) (+ res, fp32 rows), exact products, fp32 accumulation; call
+    thin_in_ok first"""
     assert A.dtype == torch.bfloat16 and A.dim() == 2 and A.is_contiguous()
     R, K = A.shape
     W = W.float().contiguous()
     C = W.size(1)
     assert W.size(0) == K
     Y = torch.empty(R, C, dtype=torch.float32, device=A.device)
-    call('hotk_thin_gemm_bias_bf16in', R * (2 * K + 4 * C), p(A), K, p(W), K, C, p(bias), p(None), 0, p(Y), C, R)
+    r_, ldr = None, 0
+    if res is not None:
+        r_, ldr, Rr, Cr = rows2d(res)
+        assert Rr == R and Cr == C and res.dtype == torch.float32
+    call('hotk_thin_gemm_bias_bf16in', R * (2 * K + 4 * C), p(A), K, p(W), K, C, p(bias), p(r_), ldr, p(Y), C, R)
     return Y
 
 

@@ -384,6 +384,9 @@ def test_thin_gemm_bf16_rows_in_vs_fp64(K, C):
     assert y.dtype == torch.float32
     assert rel_err(y.cpu(), (A.double() @ W.double() + b.double()).cpu()) < TOL
     assert rel_err(ops.thin_gemm_bf16in(A, W).cpu(), (A.double() @ W.double()).cpu()) < TOL
+    res = torch.randn(R, C + 8, device=DEV)[:, :C]          # (a residual with a padded leading dimension)
+    yr = ops.thin_gemm_bf16in(A, W, b, res)
+    assert rel_err(yr.cpu(), (A.double() @ W.double() + b.double() + res.double()).cpu()) < TOL
 
 
 @pytest.mark.parametrize('R,C', [(40001, 320), (300, 96)])
