@@ -729,7 +729,8 @@ class Basis22Full(Function):
 
 
 def _l22_forward(xs, ld, W, b_off, b_diag, plan):
-    """factored Linear(2, 2, 'light') on rows xs [R, D] -> (y [R, C], xd [Nn, D], x2 [R, 2D])"""
+    """factored Linear(2, 2, 'light') on rows xs [R, D] -> (y [R, C], xd [Nn, D], x2 [R, 2D], Wn [D, 3C]: the node-level weight
+    blocks side by side, kept for the backward pass)"""
     n, D = plan.R, W.size(0) // 5
     C = W.size(1)
     dev = xs.device
@@ -756,7 +757,7 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
         y = mm(x2, W[D:3 * D], rows=valid_rows(plan, 'e'))
         call('hotk_assemble22', 8 * n * C, p(y), C, p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off),
              p(b_diag), n, C)
-    return y, xd, x2
+    return y, xd, x2, Wn
 
 
 _L22_REDUCE = os.environ.get('HOTK_L22_REDUCE', '1') == '1'      # (A/B switch)
@@ -771,7 +772,7 @@ def l22_reduce_ok(g, x2, plan):
             and lib().hotk_linear22_bwd_reduce_supported(int(x2.size(1)), int(g.size(1)), int(plan.Nmax)) == 1)
 
 
-def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_extra=None, dx_add=None):
+def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_extra=None, dx_add=None, Wn=None):
     """gradients of the factored Linear(2, 2, 'light') from g = dy [R, C] -> (dx [R, D], dW [5D, C], db_off, db_diag).
     dxd_extra [Nn, D]: another gradient of the diagonal input rows (fc_1's), dx_add [R, D]: another gradient of all input
     rows (fc_v's); both are folded into hotk_basis22_pair_bwd's single pass over dx."""
@@ -815,7 +816,8 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         db = dyn[:, 0:2 * C].sum(0)      # (one pass over both column blocks)
         db_diag = db[0:C] if has_b[1] else None
         db_off = db[C:2 * C] if has_b[0] else None
-    Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
+    if Wn is None:
+        Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)
     dx = dW = None
     dWn = None
     if node_fused:
@@ -865,17 +867,18 @@ class Linear22Light(Function):
     def forward(ctx, x, W, b_off, b_diag, plan):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R and W.size(0) == 5 * D
-        y, xd, x2 = _l22_forward(xs, ld, W, b_off, b_diag, plan)
-        ctx.save_for_backward(xd, x2, W)
+        y, xd, x2, Wn = _l22_forward(xs, ld, W, b_off, b_diag, plan)
+        ctx.save_for_backward(xd, x2, W, Wn)
         ctx.plan, ctx.has_b, ctx.xshape = plan, (b_off is not None, b_diag is not None), x.shape
         return y.view(*x.shape[:-1], W.size(1))
 
     @staticmethod
     def backward(ctx, g):
-        xd, x2, W = ctx.saved_tensors
+        xd, x2, W, Wn = ctx.saved_tensors
         plan = ctx.plan
         g = g.contiguous().view(plan.R, W.size(1))
-        dx, dW, db_off, db_diag = _l22_backward(g, xd, x2, W, plan, ctx.has_b, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
+        dx, dW, db_off, db_diag = _l22_backward(g, xd, x2, W, plan, ctx.has_b, ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                                Wn=Wn)
         return (None if dx is None else dx.view(ctx.xshape)), dW, db_off, db_diag, None
 
 
@@ -891,7 +894,7 @@ class Proj22(Function):
     def forward(ctx, x, W1, b1, W2, b2_off, b2_diag, Wv, bv, plan, nodes_padded):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
-        h2, xd, x2 = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
+        h2, xd, x2, Wn = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
         vn, ve = valid_rows(plan, 'n'), valid_rows(plan, 'e')
         if b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn, False, b1)):
             h1 = mm(xd, W1, b1, rows=vn)   # the bias rides on the GEMM: no padding node rows, or the GEMM leaves them zero
@@ -902,14 +905,14 @@ class Proj22(Function):
         xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
         wv = Wv.t()
         v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True, rows=ve)
-        ctx.save_for_backward(xc, xd, x2, W1, W2, Wv)
+        ctx.save_for_backward(xc, xd, x2, W1, W2, Wv, Wn)
         ctx.plan, ctx.xshape, ctx.nodes_padded = plan, x.shape, nodes_padded
         ctx.has_b = (b1 is not None, b2_off is not None, b2_diag is not None)
         return h1.view(plan.B, plan.Nmax, -1), h2.view(plan.B, plan.Emax, -1), v.view(plan.B, plan.Emax, -1)
 
     @staticmethod
     def backward(ctx, dh1, dh2, dv):
-        xc, xd, x2, W1, W2, Wv = ctx.saved_tensors
+        xc, xd, x2, W1, W2, Wv, Wn = ctx.saved_tensors
         plan = ctx.plan
         D = xc.size(1)
         # fc_v: dx, dW and db from one pass over dv
@@ -935,7 +938,8 @@ class Proj22(Function):
             dxd1 = mm(g1, W1, trans_w=True, rows=vn)
         # fc_2, with the other two gradients of x folded in
         g2 = dh2.contiguous().view(plan.R, -1)
-        dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv)
+        dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv,
+                                                 Wn=Wn)
         return dx.view(ctx.xshape), dW1, db1, dW2, db_off, db_diag, dwv.t(), dbv, None, None
 
 

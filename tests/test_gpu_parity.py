@@ -1131,13 +1131,13 @@ def test_linear22_light_wide_entry_gemm_epilogue(D, C, with_bias):
     b_diag = torch.randn(C, generator=g).to(DEV) if with_bias else None
     x = G.values.reshape(plan.R, D)
     _lib.timing_begin(None)
-    y1, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+    y1, _, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
     ran = _lib.timing_end()
     assert 'hotk_gemm6_entry22' in ran and 'hotk_assemble22' not in ran
     ops._G6_ENTRY = False
     try:
         _lib.timing_begin(None)
-        y2, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+        y2, _, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
         assert 'hotk_assemble22' in _lib.timing_end()
     finally:
         ops._G6_ENTRY = True
@@ -1200,11 +1200,11 @@ def test_linear22_light_wide_entry_gemm_without_padding():
     b_off, b_diag = torch.randn(C, generator=g).to(DEV), torch.randn(C, generator=g).to(DEV)
     x = G.values.reshape(plan.R, D)
     _lib.timing_begin(None)
-    y1, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+    y1, _, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
     assert 'hotk_gemm6_entry22' in _lib.timing_end()
     ops._G6_ENTRY = False
     try:
-        y2, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
+        y2, _, _, _ = ops._l22_forward(x, D, W, b_off, b_diag, plan)
     finally:
         ops._G6_ENTRY = True
     assert torch.equal(y1, y2) and torch.isfinite(y1).all()
