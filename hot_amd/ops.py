@@ -790,8 +790,9 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
     # node gradients: [ dy on the node's diagonal | sum over off-diagonal row entries | ... column entries ]
     dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=dev)
-    dW2 = None
-    if l22_reduce_ok(g, x2, plan):
+    use_reduce = l22_reduce_ok(g, x2, plan)
+    dW2e = None
+    if use_reduce:
         # one pass over g for the three node blocks AND the entry-level weight gradient (csrc/l22bwd.hip)
         n = ctypes_long()
         check(lib().hotk_linear22_bwd_reduce_partials(plan.B, byref(n)), 'hotk_linear22_bwd_reduce_partials')
@@ -799,7 +800,7 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         call('hotk_linear22_bwd_reduce', 4 * plan.Ev * (C + 2 * D) + 12 * plan.Nn * C, p(g), C, p(x2), 2 * D, 2 * D, C,
              p(plan.kind), p(plan.rown), p(plan.coln), p(plan.g_ebeg), p(plan.g_eend), p(plan.n_nodes_dev), plan.B,
              plan.Nmax, plan.R, p(dyn), 3 * C, p(part))
-        dW2 = part[0] if n.value == 1 else part.sum(0)
+        dW2e = part[0] if n.value == 1 else part.sum(0)
     else:
         call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
         seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
@@ -826,8 +827,28 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         db_off = dbn[C:2 * C] if has_b[0] else None
         if dxd_extra is not None:
             dxd += dxd_extra
+    # the weight gradients read g and dyn only: on the side stream (small batches) next to the data-gradient chain.
+    # (Measured on the 128-molecule C2 step, 10.62 ms without: this form 10.24; with the entry-level one forked earlier,
+    # under the gather and the segment sums, fc_v's forward forked too and Proj22's joins deferred to its end: 10.32-10.37
+    # in every combination -- a fork / join pair costs about what a short overlap gains.)
+    with fork(g, want_dx and want_dw) as side:
+        if want_dw:
+            if dW2e is None:
+                dW2e = wgrad(x2, g, ve)
+            if dWn is not None:
+                pass
+            elif ones_row:
+                # (the ones column padded to four: rows of [xd | 1 0 0 0] stay 16-byte aligned for the tiled weight-gradient GEMM)
+                one = torch.zeros(xd.size(0), 4, dtype=xd.dtype, device=dev)
+                one[:, 0] = 1.
+                dWn = wgrad(torch.cat([xd, one], dim=1), dyn, vn)
+                db_diag = dWn[D, 0:C] if has_b[1] else None
+                db_off = dWn[D, C:2 * C] if has_b[0] else None
+                dWn = dWn[:D]
+            else:
+                dWn = wgrad(xd, dyn, vn)
     if want_dx:
-        if dWn is None:
+        if not node_fused:
             dxd = mm(dyn, Wn, trans_w=True, rows=vn)
             if dxd_extra is not None:
                 dxd += dxd_extra
@@ -837,20 +858,9 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
         dx = torch.empty(plan.R, D, dtype=g.dtype, device=dev)
         call('hotk_basis22_pair_bwd', 4 * plan.R * 4 * D, p(dx2), 2 * D, p(plan.kind), p(plan.tpos), p(plan.rown),
              p(dxd), D, p(dx_add), D, p(dx), D, plan.R, D)
+    side.join()
     if want_dw:
-        if dWn is not None:
-            pass
-        elif ones_row:
-            # (the ones column padded to four: rows of [xd | 1 0 0 0] stay 16-byte aligned for the tiled weight-gradient GEMM)
-            one = torch.zeros(xd.size(0), 4, dtype=xd.dtype, device=dev)
-            one[:, 0] = 1.
-            dWn = wgrad(torch.cat([xd, one], dim=1), dyn, vn)
-            db_diag = dWn[D, 0:C] if has_b[1] else None
-            db_off = dWn[D, C:2 * C] if has_b[0] else None
-            dWn = dWn[:D]
-        else:
-            dWn = wgrad(xd, dyn, vn)
-        dW = torch.cat([dWn[:, 0:C], dW2 if dW2 is not None else wgrad(x2, g, ve), dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
+        dW = torch.cat([dWn[:, 0:C], dW2e, dWn[:, C:2 * C], dWn[:, 2 * C:]], dim=0)
     return dx, dW, db_off, db_diag
 
 
@@ -894,17 +904,17 @@ class Proj22(Function):
     def forward(ctx, x, W1, b1, W2, b2_off, b2_diag, Wv, bv, plan, nodes_padded):
         xs, ld, n, D = rows2d(x)
         assert n == plan.R and W2.size(0) == 5 * D and W1.size(0) == D and Wv.size(1) == D
-        h2, xd, x2, Wn = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
         vn, ve = valid_rows(plan, 'n'), valid_rows(plan, 'e')
+        xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
+        wv = Wv.t()
+        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True, rows=ve)
+        h2, xd, x2, Wn = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
         if b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn, False, b1)):
             h1 = mm(xd, W1, b1, rows=vn)   # the bias rides on the GEMM: no padding node rows, or the GEMM leaves them zero
         else:
             h1 = mm(xd, W1, rows=vn)
             call('hotk_bias_mask_rows', 8 * plan.Nn * h1.size(1), p(h1), h1.size(1), p(plan.nkind), p(None), p(b1), plan.Nn,
                  h1.size(1))
-        xc = xs.reshape(n, D)       # (a copy only when x is a column slice of a wider tensor)
-        wv = Wv.t()
-        v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True, rows=ve)
         ctx.save_for_backward(xc, xd, x2, W1, W2, Wv, Wn)
         ctx.plan, ctx.xshape, ctx.nodes_padded = plan, x.shape, nodes_padded
         ctx.has_b = (b1 is not None, b2_off is not None, b2_diag is not None)
@@ -922,7 +932,10 @@ class Proj22(Function):
             dxv, dwv, dbv = linear_bwd_fused(dv2, xc, wv)
         else:
             ve = valid_rows(plan, 'e')
-            dxv, dwv, dbv = mm(dv2, Wv, rows=ve), wgrad(xc, dv2, ve), dv2.sum(0)
+            with fork(dv2) as side_v:
+                dwv, dbv = wgrad(xc, dv2, ve), dv2.sum(0)
+            dxv = mm(dv2, Wv, rows=ve)
+            side_v.join()
         # fc_1 (node rows)
         g1 = dh1.contiguous().view(plan.Nn, -1)
         if ctx.nodes_padded:
@@ -934,8 +947,10 @@ class Proj22(Function):
                 db1 = None
         else:
             db1 = bias_grads(g1, plan.nkind, False, True)[1] if ctx.has_b[0] else None
-            dW1 = wgrad(xd, g1, vn)
+            with fork(g1) as side_1:
+                dW1 = wgrad(xd, g1, vn)
             dxd1 = mm(g1, W1, trans_w=True, rows=vn)
+            side_1.join()
         # fc_2, with the other two gradients of x folded in
         g2 = dh2.contiguous().view(plan.R, -1)
         dx, dW2, db_off, db_diag = _l22_backward(g2, xd, x2, W2, plan, ctx.has_b[1:], True, True, dxd_extra=dxd1, dx_add=dxv,
@@ -1208,6 +1223,45 @@ _WGRAD_SPLIT_MIN = int(os.environ.get('HOTK_WGRAD_SPLIT_MIN', 1 << 12))
 _WGRAD_SPLIT_ROWS = int(os.environ.get('HOTK_WGRAD_SPLIT_ROWS', 256))
 
 
+# Small batches (the 128-molecule C2 step: 7 936 rows) leave most of the chip idle in every launch: a weight gradient has
+# no consumer inside the backward pass, so it runs on a side stream next to the data-gradient chain of the same autograd
+# node.  fork() makes the side stream wait for what is queued on the current one; join() makes the current stream wait
+# for the side stream before the node returns -- so every tensor the side work read or wrote is ordered before any later
+# use or reuse on the caller's stream (no record_stream needed), and a stream capture that contains a fork contains
+# its join.
+_SIDE_WGRAD = os.environ.get('HOTK_SIDE_WGRAD', '1') == '1'
+_SIDE_MAX_ROWS = int(os.environ.get('HOTK_SIDE_MAX_ROWS', 1 << 14))
+_side_streams = {}
+
+
+class fork:
+    """`with fork(ref) as f: ...` (body on the side stream when ref is a small CUDA batch), then `f.join()`"""
+
+    def __init__(self, ref, enabled=True):
+        self.side = None
+        if enabled and _SIDE_WGRAD and ref.is_cuda and n_rows(ref) <= _SIDE_MAX_ROWS:
+            dev = ref.device.index
+            if dev not in _side_streams:
+                _side_streams[dev] = torch.cuda.Stream(device=ref.device)
+            self.side, self.cur = _side_streams[dev], torch.cuda.current_stream(ref.device)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.side is not None:
+            self.side.wait_stream(self.cur)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.side is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self):
+        if self.side is not None:
+            self.cur.wait_stream(self.side)
+
+
 def wgrad(A, B, rows=None):
     """A^T @ B for tall operands A [R,K], B [R,N] (a reduction over R rows into a small K x N result).
     A single library GEMM has only K*N/tile workgroups to run on, so the row dimension is split into S batches
@@ -1253,16 +1307,18 @@ class RowsMatmul(Function):
             # GEMM, a split-K batched GEMM over [x | 1] and the concatenation that builds it
             dx, dw, db = linear_bwd_fused(g2.contiguous(), x2.contiguous(), w)
             return dx.view(x.shape), dw, (db if want_b else None)
-        dx = mm(g2, w, trans_w=True).view(x.shape) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1] and want_b and g2.size(1) > 2 * x2.size(1) and x2.size(0) >= (1 << 16):
-            # g is the wide operand: [x | 1]^T @ g yields dW and db in ONE pass over g
-            xa = torch.cat([x2, torch.ones(x2.size(0), 1, dtype=x2.dtype, device=x2.device)], dim=1)
-            dwa = wgrad(xa, g2)
-            dw, db = dwa[:-1], dwa[-1]
-        else:
-            dw = wgrad(x2, g2) if ctx.needs_input_grad[1] else None
-            db = g2.sum(0) if want_b else None
+        with fork(g2, ctx.needs_input_grad[0]) as f:
+            if ctx.needs_input_grad[1] and want_b and g2.size(1) > 2 * x2.size(1) and x2.size(0) >= (1 << 16):
+                # g is the wide operand: [x | 1]^T @ g yields dW and db in ONE pass over g
+                xa = torch.cat([x2, torch.ones(x2.size(0), 1, dtype=x2.dtype, device=x2.device)], dim=1)
+                dwa = wgrad(xa, g2)
+                dw, db = dwa[:-1], dwa[-1]
+            else:
+                dw = wgrad(x2, g2) if ctx.needs_input_grad[1] else None
+                db = g2.sum(0) if want_b else None
+        dx = mm(g2, w, trans_w=True).view(x.shape) if ctx.needs_input_grad[0] else None
+        f.join()
         return dx, dw, db
 
 
@@ -1423,15 +1479,17 @@ class AttnCore22(Function):
         # att as saved = the (dropped-out) input of fc_o.  dW_o = dy^T . att in the weight-gradient-only mode of
         # hotk_linear_bwd_fused (x = dy, g = att): 3.65 ms against 3.41 ms for the split-K batched GEMM before that
         # kernel's loads were made unconditional, measured again after (profiles/NOTES_r01_r02.md, old section 5)
-        if use_fused_dwo:
-            dw_o = linear_bwd_fused(att, dy.contiguous(), None)[1]
-        else:
-            dw_o = wgrad(dy, att, ve)
-        if skips_padding:
-            db = bias_grads(dy, plan.kind, True, True)
-            db_o = db[0] + db[1]
-        else:
-            db_o = dy.sum(0)
+        # (small batches: fc_o's weight and bias gradients on the side stream, under the core's backward kernels)
+        with fork(dy, getattr(plan, 'shard', None) is None) as side:
+            if use_fused_dwo:
+                dw_o = linear_bwd_fused(att, dy.contiguous(), None)[1]
+            else:
+                dw_o = wgrad(dy, att, ve)
+            if skips_padding:
+                db = bias_grads(dy, plan.kind, True, True)
+                db_o = db[0] + db[1]
+            else:
+                db_o = dy.sum(0)
         mu, keep, drop_p = ctx.drop
         AttnCore22._drop_apply(datt, plan, mu, keep, drop_p)
         padded = plan.Ev != plan.R
@@ -1473,6 +1531,7 @@ class AttnCore22(Function):
             AttnCore22._phase(a, _lib.ATTN22_BWD_KEYVAL_NODE, ws, nws, 4 * plan.Ev * (6 * 32 * 2 + 6 * 32 + 2 * 32) + 4 * kvn.numel())
         # d(raw key slots 0..5 of node i) = sum over the entries of row i of their per-entry contributions
         seg_sum_rows(ck, plan.row_seg(), None, KEEP_VALID, out=dh1[:, 128:320])
+        side.join()
         return dh1.view(h1.shape), dh2.view(h2.shape), dv.view(v.shape), None, dw_o, db_o, None, None, None
 
 
