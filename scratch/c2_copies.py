@@ -48,5 +48,6 @@ for ev in prof.events():
     agg[key][0] += 1; agg[key][1] += ev.device_time_total
 tot = sum(v[1] for v in agg.values())
 print(f'aten leaf ops with device time: {tot/1e3:.2f} ms')
-for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:45]:
+BYCOUNT = len(sys.argv) > 2
+for k, v in sorted(agg.items(), key=lambda kv: (-kv[1][0] if BYCOUNT else -kv[1][1]))[:(90 if BYCOUNT else 45)]:
     print(f'{v[1]/1e3:8.3f} ms {v[0]:4d}x  {k[0]:28s} {k[1]:62s} {k[2]}')
