@@ -356,6 +356,17 @@ def valid_rows(plan, level):
     return d[key]
 
 
+def _ones4(plan, like):
+    """the constant block [1 0 0 0] per node row, kept on the plan (two fills per use otherwise)"""
+    key = '_ones4_' + str(like.dtype)
+    d = plan.__dict__
+    if key not in d:
+        one = torch.zeros(like.size(0), 4, dtype=like.dtype, device=like.device)
+        one[:, 0] = 1.
+        d[key] = one
+    return d[key]
+
+
 def entry_records(plan):
     """int32 [n, 4] per valid entry row, ascending: {row, next valid row (R after the last), row node, column node or -1 on
     the diagonal} -- what hotk_gemm6_entry22's epilogue reads per stored row.  Built once per plan."""
@@ -839,9 +850,7 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
                 pass
             elif ones_row:
                 # (the ones column padded to four: rows of [xd | 1 0 0 0] stay 16-byte aligned for the tiled weight-gradient GEMM)
-                one = torch.zeros(xd.size(0), 4, dtype=xd.dtype, device=dev)
-                one[:, 0] = 1.
-                dWn = wgrad(torch.cat([xd, one], dim=1), dyn, vn)
+                dWn = wgrad(torch.cat([xd, _ones4(plan, xd)], dim=1), dyn, vn)
                 db_diag = dWn[D, 0:C] if has_b[1] else None
                 db_off = dWn[D, C:2 * C] if has_b[0] else None
                 dWn = dWn[:D]
