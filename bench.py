@@ -331,8 +331,16 @@ def c2_mode(args, device, world, rank, dist):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # small batches: the projections are library GEMMs of 10-40 us; pick the library's best kernel per shape during warm-up
+    from hot_amd import ops
+    from hot_amd.utils import tuning
+    tuned = None
+    if args.gemm_tuning == 'on' or (args.gemm_tuning == 'auto' and G.values.size(0) * G.values.size(1) < ops.G6_MIN_ROWS):
+        tuning.start()
     for _ in range(max(args.warmup, 2)):
         step()
+    if args.gemm_tuning != 'off':
+        tuned = tuning.finish()
     fence()
     _lib.timing_begin(None)
     step()
@@ -380,6 +388,7 @@ def c2_mode(args, device, world, rank, dist):
                        'entries_per_gpu': n_entries, 'parallelism': f'graph-minibatch dp{world}'},
             'hotk_launches_per_step': int(sum(v[1] for v in census.values())),
             'device_kernels_per_step': n_kernels,
+            'library_gemm_tuning': (f'TunableOp, {tuned} shapes chosen in warm-up (hot_amd/utils/tuning.py)' if tuned else 'off'),
             'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])[:12]},
             'cpu_reference_entries_per_s': 1.19e3,
             'cpu_reference_note': 'the real reference on 8 CPU cores, same model, 128 graphs (SURVEY section 6 / BASELINE.md)',
@@ -396,6 +405,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-kernel', default='auto', help='C-ABI entry point timed live with HIP events')
     ap.add_argument('--mode', default='graph-minibatch', choices=['graph-minibatch', 'edge-shard'])
+    ap.add_argument('--gemm-tuning', default='auto', choices=['auto', 'on', 'off'],
+                    help='--config c2: TunableOp kernel selection for the library GEMMs (auto: batches below the tiled GEMM threshold)')
     ap.add_argument('--storage', default='f32', choices=['f32', 'bf16'],
                     help="bf16: the layer's bf16 STORAGE mode (wide intermediates in bf16, fp32 accumulation; tolerance "
                          "2e-2). A second line, never the headline: the reference trains in fp32")

@@ -29,12 +29,14 @@ _SIGNATURES = {
     'hotk_mask_rows': [_P, _L, _P, _U, _F, _P, _L, _L, _L, _P],
     'hotk_seg_sum_rows': [_P, _L, _P, _P, _P, _P, _U, _P, _L, _L, _L, _L, _P],
     'hotk_seg_sum_rows_pair': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _U, _P, _P, _L, _L, _L, _L, _P],
+    'hotk_seg_sum_rows_pair_own': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _U, _P, _P, _P, _P, _L, _L, _L, _L, _P],
     'hotk_bias_mask_rows': [_P, _L, _P, _P, _P, _L, _L, _P],
     'hotk_bias_grad_workspace_bytes': [_L, _L, ctypes.POINTER(_S)],
     'hotk_bias_grad_rows': [_P, _L, _P, _P, _P, _L, _L, _P, _S, _P],
     'hotk_basis22_light_fwd': [_P, _L, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_basis22_light_bwd': [_P, _L, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _L, _P],
     'hotk_basis22_pair_fwd': [_P, _L, _P, _P, _P, _L, _L, _L, _P],
+    'hotk_basis22_pair_fwd_diag': [_P, _L, _P, _P, _P, _L, _L, _L, _P, _P, _L, _L, _P],
     'hotk_basis22_pair_bwd': [_P, _L, _P, _P, _P, _P, _L, _P, _L, _P, _L, _L, _L, _P],
     'hotk_assemble22': [_P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _P],
     'hotk_basis22_full_fwd': [_P, _L, _P, _P, _P, _P, _P, _L, _P, _L, _P, _P, _P, _P, _P, _L, _L, _L, _L, _I, _P],

@@ -177,7 +177,7 @@ __global__ void k_seg_sum_rows_pair(const float* __restrict__ src, int64_t ld_sr
                                     const int32_t* __restrict__ b_begin, const int32_t* __restrict__ b_end,
                                     const int32_t* __restrict__ b_perm, const uint8_t* __restrict__ kind, unsigned keep,
                                     float* __restrict__ out_a, float* __restrict__ out_b, int64_t ld_out, int64_t n_seg,
-                                    uint32_t CV) {
+                                    uint32_t CV, const int32_t* __restrict__ own_row, float* __restrict__ out_own) {
   using T = typename VecT<V>::type;
   const int64_t total = n_seg * CV;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -194,6 +194,12 @@ __global__ void k_seg_sum_rows_pair(const float* __restrict__ src, int64_t ld_sr
     *reinterpret_cast<T*>(out_a + s * ld_out + cv * V) = va;
     const T vb = seg_walk<V>(src, ld_src, b_begin[s], b_end[s], b_perm, kind, keep, cv * V);
     *reinterpret_cast<T*>(out_b + s * ld_out + cv * V) = vb;
+    if (own_row) {      // (hotk_seg_sum_rows_pair_own: the segment's own source row too, e.g. a node's diagonal entry)
+      const int64_t r = own_row[s];
+      T v = vzero(T());
+      if (r >= 0) v = *reinterpret_cast<const T*>(src + r * ld_src + cv * V);
+      *reinterpret_cast<T*>(out_own + s * ld_out + cv * V) = v;
+    }
   }
 }
 
@@ -387,10 +393,19 @@ __global__ void k_basis22_light_bwd(const float* __restrict__ g, int64_t ld_g, c
 template <int V>
 __global__ void k_basis22_pair_fwd(const float* __restrict__ x, int64_t ld_x, const uint8_t* __restrict__ kind,
                                    const int32_t* __restrict__ tpos, float* __restrict__ x2, int64_t ld_x2, int64_t R,
-                                   int64_t D) {
+                                   int64_t D, const int32_t* __restrict__ diag_pos, float* __restrict__ xd, int64_t ld_xd,
+                                   int64_t Nn) {
   using T = typename VecT<V>::type;
-  const int64_t DV = D / V, total = R * DV;
-  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+  const int64_t DV = D / V, total = R * DV, total_n = total + (diag_pos ? Nn * DV : 0);
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total_n; t += (int64_t)gridDim.x * blockDim.x) {
+    if (t >= total) {      // (hotk_basis22_pair_fwd_diag: xd[n] = x on node n's diagonal entry, zeros for a padding node)
+      const int64_t n = (t - total) / DV, c = (t - total - n * DV) * V;
+      const int64_t s = diag_pos[n];
+      T v = vzero(T());
+      if (s >= 0) v = *reinterpret_cast<const T*>(x + s * ld_x + c);
+      *reinterpret_cast<T*>(xd + n * ld_xd + c) = v;
+      continue;
+    }
     int64_t r = t / DV, c = (t - r * DV) * V;
     T a = vzero(T()), b = a;
     if (kind[r] == 2) {
@@ -542,25 +557,34 @@ extern "C" int hotk_seg_sum_rows(const float* src, int64_t ld_src, const int32_t
   return hotk_launch_status();
 }
 
-extern "C" int hotk_seg_sum_rows_pair(const float* src, int64_t ld_src, const int32_t* a_begin, const int32_t* a_end,
-                                      const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end,
-                                      const int32_t* b_perm, const uint8_t* kind, unsigned keep, float* out_a, float* out_b,
-                                      int64_t ld_out, int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream) {
-  HOTK_CHECK_ARG(n_seg >= 0 && C >= 0 && ld_src >= C && ld_out >= C && max_seg_len >= 0);
+extern "C" int hotk_seg_sum_rows_pair_own(const float* src, int64_t ld_src, const int32_t* a_begin, const int32_t* a_end,
+                                          const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end,
+                                          const int32_t* b_perm, const uint8_t* kind, unsigned keep, float* out_a,
+                                          float* out_b, const int32_t* own_row, float* out_own, int64_t ld_out,
+                                          int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream) {
+  HOTK_CHECK_ARG(n_seg >= 0 && C >= 0 && ld_src >= C && ld_out >= C && max_seg_len >= 0 && (!own_row == !out_own));
   if (n_seg == 0 || C == 0) return HOTK_OK;
   HOTK_CHECK_ARG(src && out_a && out_b && a_begin && a_end && a_perm && b_begin && b_end && b_perm && kind);
   if (max_seg_len > HOTK_SEG_CHUNK) return HOTK_EUNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  const bool v4 = vec4_ok(C, {ld_src, ld_out}, {src, out_a, out_b});
+  const bool v4 = vec4_ok(C, {ld_src, ld_out}, {src, out_a, out_b}) && (!out_own || hotk_aligned16(out_own));
   const int64_t CV = v4 ? C / 4 : C;
   const dim3 grid(hotk_grid(n_seg * CV, 256)), block(256);
   if (v4)
     hipLaunchKernelGGL(k_seg_sum_rows_pair<4>, grid, block, 0, st, src, ld_src, a_begin, a_end, a_perm, b_begin, b_end, b_perm,
-                       kind, keep, out_a, out_b, ld_out, n_seg, (uint32_t)CV);
+                       kind, keep, out_a, out_b, ld_out, n_seg, (uint32_t)CV, own_row, out_own);
   else
     hipLaunchKernelGGL(k_seg_sum_rows_pair<1>, grid, block, 0, st, src, ld_src, a_begin, a_end, a_perm, b_begin, b_end, b_perm,
-                       kind, keep, out_a, out_b, ld_out, n_seg, (uint32_t)CV);
+                       kind, keep, out_a, out_b, ld_out, n_seg, (uint32_t)CV, own_row, out_own);
   return hotk_launch_status();
+}
+
+extern "C" int hotk_seg_sum_rows_pair(const float* src, int64_t ld_src, const int32_t* a_begin, const int32_t* a_end,
+                                      const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end,
+                                      const int32_t* b_perm, const uint8_t* kind, unsigned keep, float* out_a, float* out_b,
+                                      int64_t ld_out, int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream) {
+  return hotk_seg_sum_rows_pair_own(src, ld_src, a_begin, a_end, a_perm, b_begin, b_end, b_perm, kind, keep, out_a, out_b,
+                                    nullptr, nullptr, ld_out, n_seg, C, max_seg_len, stream);
 }
 
 extern "C" int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* b_off,
@@ -664,20 +688,27 @@ extern "C" int hotk_basis22_light_bwd(const float* dx5, int64_t ld_dx5, const ui
   return hotk_launch_status();
 }
 
-extern "C" int hotk_basis22_pair_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
-                                     int64_t ld_x2, int64_t R, int64_t D, void* stream) {
-  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_x >= D && ld_x2 >= 2 * D);
-  if (R == 0 || D == 0) return HOTK_OK;
+extern "C" int hotk_basis22_pair_fwd_diag(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
+                                          int64_t ld_x2, int64_t R, int64_t D, const int32_t* diag_pos, float* xd,
+                                          int64_t ld_xd, int64_t Nn, void* stream) {
+  HOTK_CHECK_ARG(R >= 0 && D >= 0 && ld_x >= D && ld_x2 >= 2 * D && (!diag_pos == !xd) && (!diag_pos || (Nn >= 0 && ld_xd >= D)));
+  if (!diag_pos) Nn = 0;
+  if ((R == 0 && Nn == 0) || D == 0) return HOTK_OK;
   HOTK_CHECK_ARG(x && kind && tpos && x2);
   hipStream_t st = (hipStream_t)stream;
-  if (vec4_ok(D, {ld_x, ld_x2}, {x, x2})) {
-    hipLaunchKernelGGL(k_basis22_pair_fwd<4>, dim3(hotk_grid(R * (D / 4), 256)), dim3(256), 0, st, x, ld_x, kind, tpos, x2,
-                       ld_x2, R, D);
+  if (vec4_ok(D, {ld_x, ld_x2}, {x, x2}) && (!xd || (hotk_aligned16(xd) && (ld_xd & 3) == 0))) {
+    hipLaunchKernelGGL(k_basis22_pair_fwd<4>, dim3(hotk_grid((R + Nn) * (D / 4), 256)), dim3(256), 0, st, x, ld_x, kind, tpos,
+                       x2, ld_x2, R, D, diag_pos, xd, ld_xd, Nn);
   } else {
-    hipLaunchKernelGGL(k_basis22_pair_fwd<1>, dim3(hotk_grid(R * D, 256)), dim3(256), 0, st, x, ld_x, kind, tpos, x2,
-                       ld_x2, R, D);
+    hipLaunchKernelGGL(k_basis22_pair_fwd<1>, dim3(hotk_grid((R + Nn) * D, 256)), dim3(256), 0, st, x, ld_x, kind, tpos, x2,
+                       ld_x2, R, D, diag_pos, xd, ld_xd, Nn);
   }
   return hotk_launch_status();
+}
+
+extern "C" int hotk_basis22_pair_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
+                                     int64_t ld_x2, int64_t R, int64_t D, void* stream) {
+  return hotk_basis22_pair_fwd_diag(x, ld_x, kind, tpos, x2, ld_x2, R, D, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind, const int32_t* tpos,

@@ -122,9 +122,10 @@ def seg_sum_rows(src, seg, kind=None, keep=KEEP_VALID, out=None):
 _SEG_PAIR = os.environ.get('HOTK_SEG_PAIR', '1') == '1'
 
 
-def seg_sum_rows_pair(src, seg_a, seg_b, kind, keep, out_a, out_b):
+def seg_sum_rows_pair(src, seg_a, seg_b, kind, keep, out_a, out_b, own=None):
     """out_a / out_b = seg_sum_rows(src, seg_a / seg_b, kind, keep), the source read from HBM once (hotk_seg_sum_rows_pair);
-    lists with long segments, or without a row map, take the two separate calls"""
+    lists with long segments, or without a row map, take the two separate calls.
+    own = (rows, out_own): out_own[s] = src[rows[s]] as well (zeros where rows[s] < 0), in the same launch"""
     (ab, ae, ap, am), (bb, be, bp, bm) = seg_a, seg_b
     s, ld, n, C = rows2d(src)
     oa, lda, na, Ca = rows2d(out_a)
@@ -132,9 +133,20 @@ def seg_sum_rows_pair(src, seg_a, seg_b, kind, keep, out_a, out_b):
     ok = (_SEG_PAIR and max(am, bm) <= SEG_SPLIT and ap is not None and bp is not None and kind is not None
           and ab.numel() == bb.numel() == na == nb and lda == ldb and Ca == Cb == C
           and oa.data_ptr() == out_a.data_ptr() and ob.data_ptr() == out_b.data_ptr())
+    own_ok = False
+    if own is not None:
+        oo, ldo, no, Co = rows2d(own[1])
+        own_ok = ok and ldo == lda and no == na and Co == C and oo.data_ptr() == own[1].data_ptr() and own[0].numel() == na
+        if not own_ok:
+            assert oo.data_ptr() == own[1].data_ptr()
+            call('hotk_gather_rows', 8 * no * Co, p(s), ld, p(own[0]), p(oo), ldo, no, Co, 0)
     if not ok:
         seg_sum_rows(src, seg_a, kind, keep, out=out_a)
         seg_sum_rows(src, seg_b, kind, keep, out=out_b)
+        return
+    if own_ok:
+        call('hotk_seg_sum_rows_pair_own', 4 * C * (n + 3 * na), p(s), ld, p(ab), p(ae), p(ap), p(bb), p(be), p(bp), p(kind),
+             keep, p(oa), p(ob), p(own[0]), p(oo), lda, na, C, max(am, bm))
         return
     call('hotk_seg_sum_rows_pair', 4 * C * (n + 2 * na), p(s), ld, p(ab), p(ae), p(ap), p(bb), p(be), p(bp), p(kind), keep,
          p(oa), p(ob), lda, na, C, max(am, bm))
@@ -745,11 +757,13 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
     n, D = plan.R, W.size(0) // 5
     C = W.size(1)
     dev = xs.device
-    xd = gather_rows(xs, plan.diag_pos, plan.Nn)                                   # [Nn, D]
+    # the node rows xd [Nn, D] and the entry pairs x2 [R, 2D] from one launch
+    xd = torch.empty(plan.Nn, D, dtype=xs.dtype, device=dev)
+    x2 = torch.empty(plan.R, 2 * D, dtype=xs.dtype, device=dev)
+    call('hotk_basis22_pair_fwd_diag', 4 * n * 4 * D + 8 * plan.Nn * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D,
+         p(plan.diag_pos), p(xd), D, plan.Nn)
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)               # [D, 3C]
     yn = mm(xd, Wn, rows=valid_rows(plan, 'n'))
-    x2 = torch.empty(plan.R, 2 * D, dtype=xs.dtype, device=dev)
-    call('hotk_basis22_pair_fwd', 4 * n * 4 * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D)
     if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
         # entry GEMM with the assembly as its epilogue: y is written once
         y = torch.empty(n, C, dtype=xs.dtype, device=dev)
@@ -813,8 +827,8 @@ def _l22_backward(g, xd, x2, W, plan, has_b, want_dx=True, want_dw=True, dxd_ext
              plan.Nmax, plan.R, p(dyn), 3 * C, p(part))
         dW2e = part[0] if n.value == 1 else part.sum(0)
     else:
-        call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-        seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
+        seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:],
+                          own=(plan.diag_pos, dyn[:, 0:C]))
     # every off-diagonal entry sits in exactly one row segment and every diagonal entry on one node, so the two
     # bias gradients are column sums of the node table (N rows) instead of another pass over the E entry rows -- and
     # those column sums are one more row of the node-level weight gradient: [xd | 1]^T . dyn (no pass of their own)
@@ -993,8 +1007,8 @@ class Assemble12(Function):
         if plan.Ev != plan.R:
             g = mask_rows(g, plan.kind, KEEP_VALID, 0.0)
         dyn = torch.empty(plan.Nn, 3 * C, dtype=g.dtype, device=g.device)
-        call('hotk_gather_rows', 8 * plan.Nn * C, p(g), C, p(plan.diag_pos), p(dyn), 3 * C, plan.Nn, C, 0)
-        seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:])
+        seg_sum_rows_pair(g, plan.row_seg(), plan.col_seg(), plan.kind, KEEP_OFFDIAG, dyn[:, C:2 * C], dyn[:, 2 * C:],
+                          own=(plan.diag_pos, dyn[:, 0:C]))
         db_off = dyn[:, C:2 * C].sum(0) if ctx.has_b[0] else None
         db_diag = dyn[:, 0:C].sum(0) if ctx.has_b[1] else None
         return dyn, db_off, db_diag, None

@@ -98,6 +98,14 @@ int hotk_seg_sum_rows_pair(const float* src, int64_t ld_src, const int32_t* a_be
                            const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end, const int32_t* b_perm,
                            const uint8_t* kind, unsigned keep, float* out_a, float* out_b, int64_t ld_out, int64_t n_seg,
                            int64_t C, int64_t max_seg_len, void* stream);
+/* The same plus out_own[s] = src[own_row[s]] (zeros where own_row[s] < 0) in the same launch: with own_row = the plan's
+ * diag_pos this is hotk_gather_rows of the diagonal entries, i.e. all three node gradient blocks of Linear(2, 2, 'light')
+ * (models/sparse/linear.py:152-159 under autograd) from one launch -- small batches are bound by launches, not bytes.
+ * out_own shares ld_out; own_row / out_own both NULL: hotk_seg_sum_rows_pair. */
+int hotk_seg_sum_rows_pair_own(const float* src, int64_t ld_src, const int32_t* a_begin, const int32_t* a_end,
+                               const int32_t* a_perm, const int32_t* b_begin, const int32_t* b_end, const int32_t* b_perm,
+                               const uint8_t* kind, unsigned keep, float* out_a, float* out_b, const int32_t* own_row,
+                               float* out_own, int64_t ld_out, int64_t n_seg, int64_t C, int64_t max_seg_len, void* stream);
 /* y[r] = kind 2: y + b_off, kind 1: y + b_diag, kind 0: 0   (in place).  order-2 _Bias + apply_mask
  * (models/sparse/linear.py:297-306,345-346); order 1: pass nkind and b_diag (b_off may be NULL). */
 int hotk_bias_mask_rows(float* y, int64_t ld, const uint8_t* kind, const float* b_off, const float* b_diag,
@@ -134,6 +142,11 @@ int hotk_basis22_light_bwd(const float* dx5, int64_t ld_dx5, const uint8_t* kind
  * rows when add != NULL (another gradient of the same input -- fc_v's -- folded into the pass). */
 int hotk_basis22_pair_fwd(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
                           int64_t ld_x2, int64_t R, int64_t D, void* stream);
+/* pair_fwd plus xd[n] = x[diag_pos[n]] (zeros for a padding node, diag_pos[n] < 0) in the same launch: the node rows
+ * x_(v,v) that models/sparse/linear.py:152-153 gathers (= hotk_gather_rows over diag_pos).  xd [Nn, D], row stride ld_xd. */
+int hotk_basis22_pair_fwd_diag(const float* x, int64_t ld_x, const uint8_t* kind, const int32_t* tpos, float* x2,
+                               int64_t ld_x2, int64_t R, int64_t D, const int32_t* diag_pos, float* xd, int64_t ld_xd,
+                               int64_t Nn, void* stream);
 int hotk_basis22_pair_bwd(const float* dx2, int64_t ld_dx2, const uint8_t* kind, const int32_t* tpos,
                           const int32_t* rown, const float* dxd, int64_t ld_dxd, const float* add, int64_t ld_add,
                           float* dx, int64_t ld_dx, int64_t R, int64_t D, void* stream);

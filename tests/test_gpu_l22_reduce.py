@@ -224,7 +224,7 @@ def test_light_basis_backward_uses_it_and_matches_the_three_kernel_form():
             ops._L22_REDUCE = True
     ran1, g1 = run(True)
     ran0, g0 = run(False)
-    assert ran1['hotk_linear22_bwd_reduce'][1] == 1 and 'hotk_seg_sum_rows_pair' not in ran1
-    assert 'hotk_linear22_bwd_reduce' not in ran0 and ran0['hotk_seg_sum_rows_pair'][1] == 1
+    assert ran1['hotk_linear22_bwd_reduce'][1] == 1 and 'hotk_seg_sum_rows_pair_own' not in ran1
+    assert 'hotk_linear22_bwd_reduce' not in ran0 and ran0['hotk_seg_sum_rows_pair_own'][1] == 1
     for a, b in zip(g1, g0):
         assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())

@@ -972,6 +972,48 @@ def test_seg_sum_rows_pair_is_the_two_calls_bit_for_bit():
             assert rel_err(out[:, C:2 * C].cpu(), want.cpu()) < TOL
 
 
+def test_pair_kernels_with_the_diagonal_gather_in_the_same_launch():
+    """hotk_seg_sum_rows_pair_own and hotk_basis22_pair_fwd_diag: the pair kernels with the gather of the nodes' diagonal
+    entries (hotk_gather_rows over plan.diag_pos; linear.py:152-153 and its autograd) folded into the same launch, against
+    the separate launches bit for bit; ragged graphs (padding nodes: zeros) and BA graphs, float4 and scalar widths."""
+    from ctypes import c_void_p
+    _lib, ops, _, bs, *_ = _product()
+    p = lambda t: c_void_p(t.data_ptr())
+    for case in (_ragged_case(), _ba_case(12, 5)):
+        nfs, eis, efs, g = case
+        G0 = bs.make_batch([x.to(DEV) for x in nfs], [x.to(DEV) for x in eis], [x.to(DEV) for x in efs])
+        plan = G0.plan
+        for C in (288, 30):
+            src = torch.randn(plan.R, C, generator=g).to(DEV)
+            src[plan.kind == 0] = float('nan')          # padding rows are never read
+            ref = torch.full((plan.Nn, 3 * C), 7.0, device=DEV)
+            ops.gather_rows(src, plan.diag_pos, plan.Nn, out=ref[:, 0:C])
+            ops.seg_sum_rows_pair(src, plan.row_seg(), plan.col_seg(), plan.kind, _lib.KEEP_OFFDIAG, ref[:, C:2 * C], ref[:, 2 * C:])
+            out = torch.full((plan.Nn, 3 * C), 7.0, device=DEV)
+            _lib.timing_begin(None)
+            ops.seg_sum_rows_pair(src, plan.row_seg(), plan.col_seg(), plan.kind, _lib.KEEP_OFFDIAG, out[:, C:2 * C], out[:, 2 * C:],
+                                  own=(plan.diag_pos, out[:, 0:C]))
+            ran = _lib.timing_end()
+            fused = max(plan.max_row_deg, plan.max_col_deg) <= ops.SEG_SPLIT
+            assert ('hotk_seg_sum_rows_pair_own' in ran) == fused and ('hotk_gather_rows' in ran) == (not fused)
+            assert torch.equal(out, ref)
+            assert float(out[plan.nkind == 0].abs().max() if bool((plan.nkind == 0).any()) else 0.) == 0.0
+        for D in (32, 30):
+            x = torch.randn(plan.R, D, generator=g).to(DEV)
+            x2r = torch.full((plan.R, 2 * D), 7.0, device=DEV)
+            _lib.call('hotk_basis22_pair_fwd', 0, p(x), D, p(plan.kind), p(plan.tpos), p(x2r), 2 * D, plan.R, D)
+            xdr = ops.gather_rows(x, plan.diag_pos, plan.Nn)
+            x2 = torch.full((plan.R, 2 * D), 7.0, device=DEV)
+            xd = torch.full((plan.Nn, D), 7.0, device=DEV)
+            _lib.call('hotk_basis22_pair_fwd_diag', 0, p(x), D, p(plan.kind), p(plan.tpos), p(x2), 2 * D, plan.R, D,
+                      p(plan.diag_pos), p(xd), D, plan.Nn)
+            assert torch.equal(x2, x2r) and torch.equal(xd, xdr)
+    # argument errors: one of (diag_pos, xd) / (own_row, out_own) without the other
+    x = torch.zeros(4, 32, device=DEV)
+    with pytest.raises(_lib.HotkError):
+        _lib.call('hotk_basis22_pair_fwd_diag', 0, p(x), 32, p(plan.kind), p(plan.tpos), p(x), 64, 0, 32, p(plan.diag_pos), None, 32, 1)
+
+
 @pytest.mark.parametrize('D', [32, 100, 256, 512, 1024])
 def test_layernorm_rows_with_mask_vs_fp64(D):
     """hotk_layernorm_fwd / _bwd (csrc/norm.hip): Apply(nn.LayerNorm) of EncLayer with the padding mask folded in
