@@ -523,6 +523,8 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
     if (MODE == 0 && (b6_narrow() || ep.out_bf16)) return launch<16, 1, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st);
     return launch<16, 5, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   }
+  // (the node-level products of the light basis at the headline widths: 32 -> 384, and 32 -> 864 as 480 + 384 columns)
+  if (K == 32 && C % 96 == 0 && MODE == 0 && !ep.out_bf16) return launch<16, 3, MODE>(A, lda, W, Y, ldy, R, (int)C, ep, st);
   // wide input, narrow output: split-bf16 form while the three weight planes fit in LDS beside the result images
   const bool b6_fits = !gemm_f32() && ((size_t)3 * (K / 2) * C + (size_t)8 * 32 * OS + 2 * (size_t)C) * sizeof(float) <= 160 * 1024 && C % 2 == 0;
   if (K == 288 && C % 64 == 0) return b6_fits ? launch<144, 2, MODE, 8, true>(A, lda, W, Y, ldy, R, (int)C, ep, st)
@@ -535,7 +537,7 @@ int dispatch(const float* A, int64_t lda, const float* W, int64_t K, int64_t C, 
 }
 
 bool shape_ok(int64_t K, int64_t C) {
-  const bool known = (K == 64 && C % 96 == 0) || (K == 32 && C % 160 == 0) || (K == 288 && C % 64 == 0) ||
+  const bool known = (K == 64 && C % 96 == 0) || (K == 32 && (C % 160 == 0 || C % 96 == 0)) || (K == 288 && C % 64 == 0) ||
                      (K == 320 && C % 32 == 0);
   return known && (K * C + MAX_WAVES * 32 * OS + 2 * C) * (int64_t)sizeof(float) <= 150 * 1024;
 }

@@ -260,14 +260,13 @@ def linear_bwd_fused(g, x, w):
     check(lib().hotk_linear_bwd_partials(R, byref(n)), 'hotk_linear_bwd_partials')
     part = torch.empty(n.value, K + 2, C, dtype=torch.float32, device=g.device)
     dx = torch.empty(R, K, dtype=torch.float32, device=g.device) if w is not None else None
+    wc = None if w is None else w.float().contiguous()       # (bound to a name: alive until the launch is queued)
     if g.dtype == torch.bfloat16:
         # bf16 storage mode: g and x as stored (hotk_linear_bwd_fused_bf16), fp32 weight and results
         assert x.dtype == torch.bfloat16 and g.is_contiguous() and x.is_contiguous()
-        call('hotk_linear_bwd_fused_bf16', 2 * R * (C + K) + 4 * R * K, p(g), C, p(x), K, p(None if w is None else w.float().contiguous()),
-             K, C, p(dx), K, p(part), R)
+        call('hotk_linear_bwd_fused_bf16', 2 * R * (C + K) + 4 * R * K, p(g), C, p(x), K, p(wc), K, C, p(dx), K, p(part), R)
     else:
-        call('hotk_linear_bwd_fused', 4 * R * (C + 2 * K), p(g), C, p(x), K, p(None if w is None else w.contiguous()), K, C,
-             p(dx), K, p(part), R)
+        call('hotk_linear_bwd_fused', 4 * R * (C + 2 * K), p(g), C, p(x), K, p(wc), K, C, p(dx), K, p(part), R)
     tot = part.sum(0)
     return dx, tot[:K], tot[K] + tot[K + 1]
 
@@ -295,6 +294,45 @@ def thin_gemm(A, W, bias=None, res=None):
         r_, ldr, Rr, Cr = rows2d(res)
         assert Rr == R and Cr == C
     call('hotk_thin_gemm_bias', 4 * R * (K + C), p(a), lda, p(W), K, C, p(bias), p(r_), ldr, p(Y), C, R)
+    return Y
+
+
+_THIN_NODE = os.environ.get('HOTK_THIN_NODE', '1') == '1'      # (A/B switch)
+
+
+def _thin_blocks(K, C):
+    """column blocks of a [., K] x [K, C] product that hotk_thin_gemm_bias takes one by one (the weight block and the result
+    images share LDS: 32 x 864 does not fit, 480 + 384 do), widest first; None when C does not split"""
+    if lib().hotk_thin_gemm_supported(int(K), int(C)) == 1:
+        return [C]
+    for b in (480, 384, 320, 288, 192, 160, 96):
+        if b < C and lib().hotk_thin_gemm_supported(int(K), b) == 1:
+            rest = _thin_blocks(K, C - b)
+            if rest is not None:
+                return [b] + rest
+    return None
+
+
+def thin_blocks_ok(A, K, C):
+    """narrow-to-wide product of a tall fp32 operand with K = 32 (the node-level products of the light basis and fc_1 at the
+    headline widths: [0.98 M, 32] x [32, 864 | 384]): store-bound, the thin GEMM's row-major staged epilogue against
+    the library's tiles (0.79 ms per call for 3.4 / 1.5 GB of results)"""
+    return (_THIN_NODE and A.is_cuda and A.dtype == torch.float32 and K == 32 and C >= 8 * K and n_rows(A) >= THIN_MIN_ROWS
+            and _thin_blocks(K, C) is not None)
+
+
+def thin_gemm_blocks(A, W, bias=None):
+    """Y[R, C] = A[R, K] @ W[K, C] (+ bias), one hotk_thin_gemm_bias launch per column block of _thin_blocks"""
+    a, lda, R, K = rows2d(A)
+    C = W.size(1)
+    Y = torch.empty(R, C, dtype=A.dtype, device=A.device)
+    c0 = 0
+    for b in _thin_blocks(K, C):
+        wb = W[:, c0:c0 + b].contiguous()
+        bb = None if bias is None else bias[c0:c0 + b]
+        yb = Y[:, c0:c0 + b]
+        call('hotk_thin_gemm_bias', 4 * R * (K + b), p(a), lda, p(wb), K, b, p(bb), p(None), 0, p(yb), C, R)
+        c0 += b
     return Y
 
 
@@ -763,11 +801,12 @@ def _l22_forward(xs, ld, W, b_off, b_diag, plan):
     call('hotk_basis22_pair_fwd_diag', 4 * n * 4 * D + 8 * plan.Nn * D, p(xs), ld, p(plan.kind), p(plan.tpos), p(x2), 2 * D, n, D,
          p(plan.diag_pos), p(xd), D, plan.Nn)
     Wn = torch.cat([W[0:D], W[3 * D:4 * D], W[4 * D:5 * D]], dim=1)               # [D, 3C]
-    yn = mm(xd, Wn, rows=valid_rows(plan, 'n'))
+    yn = thin_gemm_blocks(xd, Wn) if thin_blocks_ok(xd, D, 3 * C) else mm(xd, Wn, rows=valid_rows(plan, 'n'))
     if thin_ok(n, 2 * D, C) and plan.Nn * 3 * C < (1 << 32):
         # entry GEMM with the assembly as its epilogue: y is written once
         y = torch.empty(n, C, dtype=xs.dtype, device=dev)
-        call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(W[D:3 * D].contiguous()), 2 * D, C, p(yn), 3 * C,
+        w2 = W[D:3 * D].contiguous()
+        call('hotk_linear22_entry_fwd', 4 * n * (2 * D + C), p(x2), 2 * D, p(w2), 2 * D, C, p(yn), 3 * C,
              p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(y), C, n, plan.Nn)
     elif entry22_ok(x2, 2 * D, C, b_off, b_diag, plan):
         # the same on the tiled GEMM (wide layers): products over the valid rows, assembly in the epilogue, padding rows zero
@@ -932,7 +971,9 @@ class Proj22(Function):
         wv = Wv.t()
         v = thin_gemm(xc, wv, bv) if thin_wide_ok(n, D, wv.size(1)) else mm(xc, Wv, bv, trans_w=True, rows=ve)
         h2, xd, x2, Wn = _l22_forward(xs, ld, W2, b2_off, b2_diag, plan)
-        if b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn, False, b1)):
+        if b1 is not None and not nodes_padded and thin_blocks_ok(xd, D, W1.size(1)):
+            h1 = thin_gemm_blocks(xd, W1, b1)
+        elif b1 is not None and (not nodes_padded or mm_masks(xd, W1, vn, False, b1)):
             h1 = mm(xd, W1, b1, rows=vn)   # the bias rides on the GEMM: no padding node rows, or the GEMM leaves them zero
         else:
             h1 = mm(xd, W1, rows=vn)
@@ -1609,7 +1650,8 @@ class AttnLayer22BF16(Function):
         if thin_ok(R, 2 * D, C) and Nn * 3 * C < (1 << 32):
             # entry GEMM (fp32 operands, split-bf16 MFMAs) with the assembly as its epilogue, rounded to bf16 at the store
             h2 = torch.empty(R, C, dtype=bf, device=dev)
-            call('hotk_linear22_entry_fwd_bf16', R * (4 * 2 * D + 2 * C), p(x2), 2 * D, p(W2[D:3 * D].contiguous()), 2 * D, C,
+            w2 = W2[D:3 * D].contiguous()
+            call('hotk_linear22_entry_fwd_bf16', R * (4 * 2 * D + 2 * C), p(x2), 2 * D, p(w2), 2 * D, C,
                  p(yn), 3 * C, p(plan.kind), p(plan.rown), p(plan.coln), p(b_off), p(b_diag), p(h2), C, R, Nn)
         else:
             h2 = x2b @ W2[D:3 * D].to(bf)

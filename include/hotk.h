@@ -180,7 +180,8 @@ int hotk_basis22_full_bwd_gather(const float* w, int64_t ld_w, const uint8_t* ki
  *   Y[R, C] = A[R, K] @ W[K, C] (+ bias[C]) (+ res[R, C])        W row-major [K, C]
  * stands in for nn.Linear / `V @ weight` and their data gradients over the ~1e7 entry rows of a batch
  * (models/sparse/kernelattn.py:46-51,65-82; models/sparse/linear.py:46-48).  Shapes: (K, C) with K in {32, 64, 288, 320}
- * and C a multiple of {160, 96, 64, 32} resp. (the C1 layer), K*C*4 <= 150 KB; hotk_thin_gemm_supported tells, other
+ * and C a multiple of {160 or 96, 96, 64, 32} resp. (the C1 layer; K = 32 with C % 96 == 0: the node-level products 32 -> 384
+ * and, as column blocks 480 + 384 with Y / bias offset by the caller, 32 -> 864), K*C*4 <= 150 KB; hotk_thin_gemm_supported tells, other
  * shapes return HOTK_EUNSUPPORTED (the Python layer then uses the library GEMM).  A rows 16-byte aligned.
  * hotk_linear22_entry_fwd is the entry GEMM of the factored Linear(2,2,'light') with hotk_assemble22's epilogue applied
  * to the accumulators (one pass over Y instead of three); Nn = rows of the node table yn (Nn * ld_yn < 2^32, else

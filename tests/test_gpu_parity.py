@@ -312,7 +312,7 @@ def test_uniform_extension_vs_reference(name):
     assert torch.equal(y2, y1.flip(0))
 
 
-@pytest.mark.parametrize('K,C', [(64, 288), (32, 320), (288, 64), (320, 32), (64, 96)])
+@pytest.mark.parametrize('K,C', [(64, 288), (32, 320), (288, 64), (320, 32), (64, 96), (32, 384), (32, 480)])
 def test_thin_gemm_vs_fp64(K, C):
     """hand-written LDS-resident-weight MFMA GEMM (csrc/gemm.hip) against an fp64 product, with bias and residual, on a
     row count that is not a multiple of the 128-row tile, with a padded leading dimension and a column-sliced residual"""
@@ -329,6 +329,27 @@ def test_thin_gemm_vs_fp64(K, C):
         assert rel_err(y.cpu(), ref.float().cpu()) < TOL, (R, K, C)
         y0 = ops.thin_gemm(A, W)
         assert rel_err(y0.cpu(), (A.double() @ W.double()).float().cpu()) < TOL
+
+
+@pytest.mark.parametrize('C', [864, 384, 1056])
+def test_thin_gemm_column_blocks_vs_fp64(C):
+    """ops.thin_gemm_blocks: a [R, 32] x [32, C] product as one hotk_thin_gemm_bias launch per column block (864 = 480 + 384:
+    the node-level product of Linear(2,2,'light') at the headline widths; 384: fc_1's), each block writing its column
+    slice of the result, with and without bias, against float64; and a width that does not split (32 x 200)"""
+    _lib, ops, *_ = _product()
+    torch.manual_seed(C)
+    R = 40037
+    A = torch.randn(R, 36, device=DEV)[:, :32]           # ld = 36
+    W = torch.randn(32, C, device=DEV)
+    b = torch.randn(C, device=DEV)
+    assert ops.thin_blocks_ok(A, 32, C) and sum(ops._thin_blocks(32, C)) == C
+    assert ops._thin_blocks(32, 200) is None and not ops.thin_blocks_ok(A, 32, 200)
+    _lib.timing_begin(None)
+    y = ops.thin_gemm_blocks(A, W, b)
+    ran = _lib.timing_end()
+    assert ran['hotk_thin_gemm_bias'][1] == len(ops._thin_blocks(32, C))
+    assert rel_err(y.cpu(), (A.double() @ W.double() + b.double()).cpu()) < TOL
+    assert rel_err(ops.thin_gemm_blocks(A, W).cpu(), (A.double() @ W.double()).cpu()) < TOL
 
 
 @pytest.mark.parametrize('R,C', [(70001, 320), (33000, 64), (255, 320), (40003, 864), (33001, 384), (1001, 32), (513, 1024),
