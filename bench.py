@@ -225,6 +225,7 @@ def edge_shard_mode(args, device, world, rank, dist):
             'exchange_bytes_per_step_per_rank': 2 * 4 * (2 * G.plan.Nn * 1152 + G.plan.Nn * 128) if world > 1 else 0,
             'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
             'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'preconditioned': args.preconditioned,      # (see precondition(): device memory written once by an earlier process)
         }), flush=True)
 
 
@@ -393,7 +394,37 @@ def c2_mode(args, device, world, rank, dist):
             'cpu_reference_entries_per_s': 1.19e3,
             'cpu_reference_note': 'the real reference on 8 CPU cores, same model, 128 graphs (SURVEY section 6 / BASELINE.md)',
             'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'preconditioned': args.preconditioned,      # (see precondition(): device memory written once by an earlier process)
         }), flush=True)
+
+
+_PRECONDITION = """
+import sys, torch
+dev = torch.device('cuda', int(sys.argv[1]))
+free, _ = torch.cuda.mem_get_info(dev)
+n = min(int(float(sys.argv[2]) * 2 ** 30), int(0.8 * free))
+x = torch.empty(n, dtype=torch.uint8, device=dev)
+x.zero_()
+torch.cuda.synchronize(dev)
+"""
+
+
+def precondition(local_rank, gib=100.0):
+    """Device memory that no process has used since the box came up is slower: the FIRST process to use the GPU of a fresh
+    box runs every kernel of the step about 2 % slower than any later process (68.0-68.3 against 66.1-66.9 ms per step on
+    five boxes; not a matter of warm-up length -- 25 or 100 warm-up steps: 67.6 / 68.1 -- nor of creating a context first:
+    68.0; writing 200-270 GiB and freeing them inside the measuring process: 66.9 / 68.1).  After a short-lived process has
+    written ~100 GiB of it and exited, the next process runs at the later-process speed (66.7).  So, before this process
+    creates its own context, a child does exactly that.  Nothing of the measured job runs there; --no-precondition
+    skips it, and the result line says which was done."""
+    import subprocess
+    t0 = time.perf_counter()
+    try:
+        rc = subprocess.run([sys.executable, '-c', _PRECONDITION, str(local_rank), str(gib)], timeout=300,
+                            stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL).returncode
+    except Exception:
+        rc = -1
+    return {'child_wrote_GiB': gib, 'child_rc': rc, 'seconds': round(time.perf_counter() - t0, 1)}
 
 
 def main():
@@ -417,6 +448,9 @@ def main():
                          'enc-small training step (a second line)')
     ap.add_argument('--molecules', type=int, default=128, help='--config c2: molecules per GPU (enc-small.sh ships 128)')
     ap.add_argument('--no-graph', action='store_true', help='--config c2: eager steps instead of HIP-graph replay')
+    ap.add_argument('--no-precondition', action='store_true',
+                    help='do not let a short-lived child process write device memory before this process uses the GPU '
+                         '(see precondition(): the first process on a fresh box is ~2 %% slower)')
     ap.add_argument('--sweep', action='store_true', help='run_perf_tests.py-style size sweep (SK / SL curves) instead')
     ap.add_argument('--sweep-max-n', type=int, default=None)
     args = ap.parse_args()
@@ -433,6 +467,8 @@ def main():
         raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); n_gpus in the result '
                          f'line must equal --gpus')
     dry = os.environ.get('HOTK_BENCH_DRY_LAUNCH') == '1'
+    # (before anything in this process touches the GPU)
+    args.preconditioned = None if (dry or args.no_precondition or args.sweep) else precondition(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -566,6 +602,7 @@ def main():
             'roofline': roof,
             'k1_plan_build_ms': round(k1_ms, 3),
             'peak_mem_GiB': round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
+            'preconditioned': args.preconditioned,      # (see precondition(): device memory written once by an earlier process)
             'kernel_census_ms_per_step': {k: round(v[0], 3) for k, v in sorted(census.items(), key=lambda kv: -kv[1][0])},
         }
         if args.no_cpu_baseline or world > 1:
