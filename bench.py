@@ -468,7 +468,10 @@ def main():
                          f'line must equal --gpus')
     dry = os.environ.get('HOTK_BENCH_DRY_LAUNCH') == '1'
     # (before anything in this process touches the GPU)
-    args.preconditioned = None if (dry or args.no_precondition or args.sweep) else precondition(local_rank)
+    # (not under rocprofv3: its preloaded tool library has initialised the GPU in this process already, and a process that
+    # has must not start another program)
+    profiled = 'rocprof' in os.environ.get('LD_PRELOAD', '') or any(k.startswith(('ROCPROF', 'ROCP_')) for k in os.environ)
+    args.preconditioned = None if (dry or args.no_precondition or args.sweep or profiled) else precondition(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -6,7 +6,7 @@ mkdir -p gpurun_out/$tag
 i=0
 for ctrs in "SQ_WAVES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  timeout -s KILL 170 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/$tag/p$i -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/$tag/p$i.log 2>&1 || { tail -3 gpurun_out/$tag/p$i.log; exit 1; }
+  timeout -s KILL 170 rocprofv3 --pmc $ctrs --output-format csv -d gpurun_out/$tag/p$i -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-precondition > gpurun_out/$tag/p$i.log 2>&1 || { tail -3 gpurun_out/$tag/p$i.log; exit 1; }
 done
 python - gpurun_out/$tag <<'PY' > gpurun_out/$tag.txt
 import sys, glob, csv, collections
