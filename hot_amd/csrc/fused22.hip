@@ -1056,7 +1056,7 @@ __global__ __launch_bounds__(TPB) void k_graph_apply_bwd(A a, float* __restrict_
 #ifndef HOTK_GB_ROWS
 #define HOTK_GB_ROWS 64   /* rows per wave: the two d(KV) sums (50 registers) are loaded once per chunk; 16: 4.4 ms, 32: 3.8, 64: 3.6 */
 #endif
-constexpr int GB_ROWS = HOTK_GB_ROWS, GB_ROWS_SMALL = 16;   // SMALL: batches with too few 64-row chunks to fill the chip
+constexpr int GB_ROWS = HOTK_GB_ROWS, GB_ROWS_SMALL = 16, GB_ROWS_TINY = 4;   // SMALL: batches with too few 64-row chunks to fill the chip
 template <class ST, bool DIAG>
 __device__ __forceinline__ void graphsum_bwd_rows(const LaneB& L, const A& a, float* stage, int64_t b, int64_t ra,
                                                   int64_t rb) {
@@ -1675,7 +1675,13 @@ inline unsigned* tk_slot(unsigned* tickets, int i) { return tickets ? tickets + 
 
 template <class ST>
 void launch_graphsum_bwd(hipStream_t st, const A* a, unsigned* tickets) {
-  if (a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS) < 2048) {
+  if (a->B * ((a->Emax + GB_ROWS_SMALL - 1) / GB_ROWS_SMALL) < 1024) {
+    // a few hundred chunks of 16: the kernel's time is one wave's chain of rows (128 PCQM molecules: 512 waves x 16 rows,
+    // 27 us) -- four rows per wave
+    constexpr int RW = GB_ROWS_TINY;
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), work_grid(a->B * ((a->Nmax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 4));
+    hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), work_grid(a->B * ((a->Emax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 5));
+  } else if (a->B * ((a->Emax + GB_ROWS - 1) / GB_ROWS) < 2048) {
     constexpr int RW = GB_ROWS_SMALL;
     hipLaunchKernelGGL((k_graphsum_bwd<ST, true, RW>), work_grid(a->B * ((a->Nmax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 4));
     hipLaunchKernelGGL((k_graphsum_bwd<ST, false, RW>), work_grid(a->B * ((a->Emax + RW - 1) / RW), tickets), dim3(TPB), 0, st, *a, tk_slot(tickets, 5));
